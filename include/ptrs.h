@@ -196,6 +196,7 @@ typedef struct PtrsStats {
 typedef struct PtrsScene PtrsScene;
 
 int ptrs_abi_version(void);
+int ptrs_abi_sizeof(int which); /* sizeof the ABI structs as compiled (binding self-check) */
 const char *ptrs_last_error(void);
 
 /* Uploads the scene and (unless desc->bvh_nodes is given) builds the accelerator on the host.
@@ -203,6 +204,8 @@ const char *ptrs_last_error(void);
  * (src/pathtracer/gpu/optix.rs:160-290) which consumes the same flat mesh arrays. */
 int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out);
 void ptrs_scene_destroy(PtrsScene *scene);
+/* accelerator facts (the reference logs these: accelerator.rs:131-148); any pointer may be NULL */
+int ptrs_scene_info(PtrsScene *scene, uint64_t *n_nodes, uint64_t *max_depth, uint64_t *n_tris);
 
 /* PathIntegrator::render (integrator.rs:536-642).  ACCUMULATES into film_inout (host memory,
  * width*height pixels) like Film::merge_film_tile (film.rs:213-228); rows outside

@@ -1,0 +1,48 @@
+"""Builds the HIP shared library (libptrs_hip.so) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off (and no fast-math) is part of the contract:
+the kernels must produce the same binary32 results as the CPU oracle (csrc/pt_vec.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libptrs_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-parameter"]
+
+
+def _gen_tables_inc():
+    src = os.path.join(ROOT, "data", "sobol_tables.bin")
+    dst = os.path.join(CSRC, "sobol_tables_data.inc")
+    if os.path.exists(dst) and os.path.getmtime(dst) >= os.path.getmtime(src):
+        return
+    data = open(src, "rb").read()
+    with open(dst, "w") as f:
+        for i in range(0, len(data), 32):
+            f.write(",".join(str(b) for b in data[i:i + 32]) + ",\n")
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hip", ".inc"))] + [
+        os.path.join(ROOT, "include", "ptrs.h"), os.path.join(ROOT, "include", "ptrs_detmath.h")]
+
+
+def build(force=False, extra_flags=(), verbose=False):
+    _gen_tables_inc()
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in sources()):
+        return LIB
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", LIB, os.path.join(CSRC, "ptrs_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True, extra_flags=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])
+    print("built", LIB)

@@ -1,0 +1,264 @@
+// pt_host_scene.h -- host side of ptrs_scene_create: validates the flat description
+// (include/ptrs.h), builds the BVH, and lays the scene out in the device formats of pt_scene.h.
+//
+// The accelerator is this library's own builder (binned SAH, 12 bins, leaves of <= 4 triangles,
+// the same cost model as src/pathtracer/accelerator.rs:156-307 so tree quality is comparable);
+// closest-hit results do not depend on the tree.  A caller that already holds the
+// reference's flattened tree can pass it through PtrsSceneDesc::bvh_nodes instead.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrs.h"
+#include "pt_tri.h"
+
+namespace pt {
+
+struct HostScene {
+    std::vector<DNode> nodes;
+    std::vector<DTri> tris;
+    std::vector<DTriShade> shade;
+    std::vector<DMaterial> mats;
+    std::vector<DTexture> texs;
+    std::vector<DTexLevel> levels;
+    std::vector<float> texdata;
+    std::vector<DLight> lights;
+    std::vector<float> distdata;
+    std::vector<uint32_t> inf_lights;
+    uint32_t max_depth = 0;
+    bool kinds_present[7] = {false, false, false, false, false, false, false};
+};
+
+namespace hostbvh {
+struct Box { float lo[3], hi[3]; };
+inline Box empty_box() { Box b; for (int k = 0; k < 3; ++k) { b.lo[k] = 3.402823466e38f; b.hi[k] = -3.402823466e38f; } return b; }
+inline void grow(Box &b, const Box &o) { for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); } }
+inline void grow_pt(Box &b, const float *p) { for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], p[k]); b.hi[k] = std::max(b.hi[k], p[k]); } }
+inline float area(const Box &b) { float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2]; return 2.0f * (dx * dy + dx * dz + dy * dz); }
+
+struct Item { uint32_t prim; float c[3]; Box b; };
+
+// recursive top-down build emitting depth-first nodes (first child = parent + 1)
+struct Builder {
+    std::vector<Item> items;
+    std::vector<DNode> *nodes;
+    std::vector<uint32_t> order;
+    uint32_t max_depth = 0;
+    bool overflow = false;
+
+    uint32_t build(size_t lo, size_t hi, uint32_t depth) {
+        uint32_t me = (uint32_t)nodes->size();
+        nodes->push_back(DNode());
+        max_depth = std::max(max_depth, depth);
+        Box bounds = empty_box(), cb = empty_box();
+        for (size_t i = lo; i < hi; ++i) { grow(bounds, items[i].b); grow_pt(cb, items[i].c); }
+        const size_t n = hi - lo;
+        int axis = 0;
+        { float ex[3] = {cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2]};
+          if (ex[1] > ex[axis]) axis = 1;
+          if (ex[2] > ex[axis]) axis = 2; }
+        size_t mid = lo;
+        bool leaf = (n == 1) || (cb.hi[axis] == cb.lo[axis]);
+        if (!leaf) {
+            if (n <= 2) {
+                mid = (lo + hi) / 2;
+                std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi, [axis](const Item &a, const Item &b) { return a.c[axis] < b.c[axis]; });
+            } else {
+                const int NB = 12;
+                size_t cnt[NB] = {0}; Box bb[NB];
+                for (int k = 0; k < NB; ++k) bb[k] = empty_box();
+                const float inv = 1.0f / (cb.hi[axis] - cb.lo[axis]);
+                auto bin_of = [&](const Item &it) { int b = (int)((float)NB * ((it.c[axis] - cb.lo[axis]) * inv)); return b >= NB ? NB - 1 : (b < 0 ? 0 : b); };
+                for (size_t i = lo; i < hi; ++i) { int b = bin_of(items[i]); cnt[b]++; grow(bb[b], items[i].b); }
+                // sweep from both ends
+                float left_area[NB - 1], right_area[NB - 1]; size_t left_cnt[NB - 1], right_cnt[NB - 1];
+                { Box acc = empty_box(); size_t c = 0; for (int k = 0; k < NB - 1; ++k) { grow(acc, bb[k]); c += cnt[k]; left_area[k] = c ? area(acc) : 0.0f; left_cnt[k] = c; } }
+                { Box acc = empty_box(); size_t c = 0; for (int k = NB - 1; k >= 1; --k) { grow(acc, bb[k]); c += cnt[k]; right_area[k - 1] = c ? area(acc) : 0.0f; right_cnt[k - 1] = c; } }
+                const float inv_area = 1.0f / area(bounds);
+                int best = 0; float best_cost = 3.402823466e38f;
+                for (int k = 0; k < NB - 1; ++k) {
+                    float cst = 1.0f + ((float)left_cnt[k] * left_area[k] + (float)right_cnt[k] * right_area[k]) * inv_area;
+                    if (cst < best_cost) { best_cost = cst; best = k; }
+                }
+                if (n > 4 || best_cost < (float)n) {
+                    auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item &x) { return bin_of(x) <= best; });
+                    mid = (size_t)(it - items.begin());
+                    if (mid == lo || mid == hi) { // numerically empty side: fall back to a median split
+                        mid = (lo + hi) / 2;
+                        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi, [axis](const Item &a, const Item &b) { return a.c[axis] < b.c[axis]; });
+                    }
+                } else leaf = true;
+            }
+        }
+        DNode nd;
+        nd.pmin[0] = bounds.lo[0]; nd.pmin[1] = bounds.lo[1]; nd.pmin[2] = bounds.lo[2];
+        nd.pmax0 = bounds.hi[0]; nd.pmax1 = bounds.hi[1]; nd.pmax2 = bounds.hi[2];
+        if (leaf) {
+            nd.offset = (uint32_t)order.size();
+            if (n > 0xffffu) overflow = true; // only possible when > 65535 centroids coincide
+            nd.meta = (uint32_t)(n & 0xffffu);
+            for (size_t i = lo; i < hi; ++i) order.push_back(items[i].prim);
+            (*nodes)[me] = nd;
+            return me;
+        }
+        build(lo, mid, depth + 1);
+        uint32_t second = build(mid, hi, depth + 1);
+        nd.offset = second; nd.meta = (uint32_t)axis << 16;
+        (*nodes)[me] = nd;
+        return me;
+    }
+};
+} // namespace hostbvh
+
+inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &err) {
+    auto bad = [&](const char *m) { err = m; return (int)PTRS_ERR_INVALID; };
+    if (d.n_meshes && !d.meshes) return bad("meshes is NULL");
+    // ---- textures -------------------------------------------------------------------------------
+    H.texs.resize(d.n_textures);
+    for (uint32_t i = 0; i < d.n_textures; ++i) {
+        const PtrsTexture &s = d.textures[i]; DTexture &t = H.texs[i];
+        std::memset(&t, 0, sizeof(t));
+        if (s.kind < 0 || s.kind > 2 || (s.channels != 1 && s.channels != 3)) return bad("bad texture record");
+        t.kind = s.kind; t.channels = s.channels;
+        for (int c = 0; c < 3; ++c) { t.value[c] = s.value[c]; t.value2[c] = s.value2[c]; }
+        t.su = s.su; t.sv = s.sv; t.du = s.du; t.dv = s.dv; t.wrap = s.wrap;
+        if (s.kind == PTRS_TEX_IMAGE) {
+            if (s.n_levels <= 0 || !s.level_data || !s.level_cols || !s.level_rows) return bad("image texture without pyramid");
+            t.n_levels = s.n_levels; t.first_level = (uint32_t)H.levels.size();
+            for (int l = 0; l < s.n_levels; ++l) {
+                DTexLevel L; L.offset = H.texdata.size(); L.cols = s.level_cols[l]; L.rows = s.level_rows[l];
+                if (L.cols <= 0 || L.rows <= 0) return bad("empty texture level");
+                size_t n = (size_t)L.cols * (size_t)L.rows * (size_t)s.channels;
+                H.texdata.insert(H.texdata.end(), s.level_data[l], s.level_data[l] + n);
+                H.levels.push_back(L);
+            }
+        }
+    }
+    auto tex_ok = [&](int32_t id, int ch) { return id >= 0 && (uint32_t)id < d.n_textures && d.textures[id].channels == ch; };
+    // ---- materials ------------------------------------------------------------------------------
+    H.mats.resize(d.n_materials);
+    for (uint32_t i = 0; i < d.n_materials; ++i) {
+        const PtrsMaterial &s = d.materials[i]; DMaterial &m = H.mats[i];
+        m.kind = s.kind; m.flags = s.flags; m.inner = s.inner;
+        for (int k = 0; k < 6; ++k) m.tex[k] = s.tex[k];
+        bool ok = true;
+        switch (s.kind) {
+            case PTRS_MAT_MATTE: ok = tex_ok(s.tex[0], 3); break;
+            case PTRS_MAT_MIRROR: break;
+            case PTRS_MAT_GLASS: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 3) && tex_ok(s.tex[2], 1); break;
+            case PTRS_MAT_METAL: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 3) && tex_ok(s.tex[2], 3) && ((tex_ok(s.tex[4], 1) && tex_ok(s.tex[5], 1)) || tex_ok(s.tex[3], 1)); break;
+            case PTRS_MAT_DISNEY: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 1) && tex_ok(s.tex[2], 1) && tex_ok(s.tex[3], 1); break;
+            case PTRS_MAT_SUBSTRATE: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 3) && tex_ok(s.tex[2], 1) && tex_ok(s.tex[3], 1); break;
+            case PTRS_MAT_NORMAL: ok = tex_ok(s.tex[0], 3) && s.inner >= 0 && (uint32_t)s.inner < d.n_materials && (uint32_t)s.inner != i; break;
+            default: err = "unknown material kind"; return PTRS_ERR_UNSUPPORTED;
+        }
+        if (!ok) return bad("material references a missing texture / inner material");
+    }
+    // ---- triangles ------------------------------------------------------------------------------
+    std::vector<uint32_t> mesh_first(d.n_meshes);
+    size_t n_tris = 0;
+    for (uint32_t m = 0; m < d.n_meshes; ++m) { mesh_first[m] = (uint32_t)n_tris; n_tris += d.meshes[m].n_tris; }
+    if (n_tris >= 0x7fffffffull) return bad("too many triangles");
+    H.shade.resize(n_tris);
+    for (uint32_t m = 0; m < d.n_meshes; ++m) {
+        const PtrsMesh &s = d.meshes[m];
+        if (!s.pos || !s.indices) return bad("mesh without positions / indices");
+        if (s.material < 0 || (uint32_t)s.material >= d.n_materials) return bad("mesh material out of range");
+        if (s.alpha_mask_tex >= 0) { err = "alpha-mask textures are not implemented in this build"; return PTRS_ERR_UNSUPPORTED; }
+        int mi = s.material;
+        for (int g = 0; g < 4 && H.mats[mi].kind == PTRS_MAT_NORMAL; ++g) mi = H.mats[mi].inner;
+        const int bucket = H.mats[mi].kind;
+        if (bucket == PTRS_MAT_NORMAL) return bad("normal materials nested too deeply");
+        H.kinds_present[bucket] = true;
+        for (uint32_t t = 0; t < s.n_tris; ++t) {
+            DTriShade &T = H.shade[mesh_first[m] + t];
+            std::memset(&T, 0, sizeof(T));
+            uint32_t v[3] = {s.indices[3 * t], s.indices[3 * t + 1], s.indices[3 * t + 2]};
+            for (int k = 0; k < 3; ++k) if (v[k] >= s.n_verts) return bad("vertex index out of range");
+            float *P[3] = {T.p0, T.p1, T.p2}, *N[3] = {T.n0, T.n1, T.n2}, *S[3] = {T.s0, T.s1, T.s2}, *UV[3] = {T.uv0, T.uv1, T.uv2};
+            const float duv[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}}; // shape.rs:41-46
+            for (int k = 0; k < 3; ++k) {
+                for (int c = 0; c < 3; ++c) {
+                    P[k][c] = s.pos[3 * v[k] + c];
+                    if (s.normal) N[k][c] = s.normal[3 * v[k] + c];
+                    if (s.tangent) S[k][c] = s.tangent[3 * v[k] + c];
+                }
+                for (int c = 0; c < 2; ++c) UV[k][c] = s.uv ? s.uv[2 * v[k] + c] : duv[k][c];
+            }
+            T.material = s.material; T.light = -1; T.alpha_tex = s.alpha_mask_tex;
+            T.flags = (s.normal ? TRI_HAS_NORMAL : 0u) | (s.tangent ? TRI_HAS_TANGENT : 0u) | (s.reverse_orientation ? TRI_REVERSE : 0u) | (s.transform_swaps_handedness ? TRI_SWAPS : 0u);
+            f3 dpdu, dpdv;
+            if (!tri_dpduv(ld3(T.p0), ld3(T.p1), ld3(T.p2), mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), dpdu, dpdv)) T.flags |= TRI_DEGENERATE;
+        }
+    }
+    // ---- lights ---------------------------------------------------------------------------------
+    H.lights.resize(d.n_lights);
+    for (uint32_t i = 0; i < d.n_lights; ++i) {
+        const PtrsLight &s = d.lights[i]; DLight &L = H.lights[i];
+        std::memset(&L, 0, sizeof(L));
+        L.kind = s.kind; L.tri = -1; L.ke_tex = -1; L.lmap_tex = -1;
+        for (int c = 0; c < 3; ++c) { L.v[c] = s.v[c]; L.c[c] = s.c[c]; }
+        L.world_radius = s.world_radius;
+        if (s.kind == PTRS_LIGHT_AREA) {
+            if (s.mesh >= d.n_meshes || s.tri >= d.meshes[s.mesh].n_tris || !tex_ok(s.ke_tex, 3)) return bad("bad area light record");
+            L.tri = (int32_t)(mesh_first[s.mesh] + s.tri); L.ke_tex = s.ke_tex;
+            DTriShade &T = H.shade[L.tri];
+            T.light = (int32_t)i;
+            L.area = 0.5f * len(cross(ld3(T.p1) - ld3(T.p0), ld3(T.p2) - ld3(T.p0))); // Triangle::area, shape.rs:533-539
+        } else if (s.kind == PTRS_LIGHT_INFINITE) {
+            if (!tex_ok(s.lmap_tex, 3) || d.textures[s.lmap_tex].kind != PTRS_TEX_IMAGE || s.dist_nu <= 0 || s.dist_nv <= 0 || !s.dist_func || !s.dist_cdf || !s.dist_func_int || !s.marg_cdf) return bad("bad infinite light record");
+            L.lmap_tex = s.lmap_tex;
+            std::memcpy(L.l2w, s.light_to_world, 48); std::memcpy(L.w2l, s.world_to_light, 48);
+            L.nu = s.dist_nu; L.nv = s.dist_nv; L.marg_int = s.marg_func_int;
+            size_t nu = (size_t)s.dist_nu, nv = (size_t)s.dist_nv;
+            L.func_off = (uint32_t)H.distdata.size(); H.distdata.insert(H.distdata.end(), s.dist_func, s.dist_func + nu * nv);
+            L.cdf_off = (uint32_t)H.distdata.size(); H.distdata.insert(H.distdata.end(), s.dist_cdf, s.dist_cdf + (nu + 1) * nv);
+            L.fint_off = (uint32_t)H.distdata.size(); H.distdata.insert(H.distdata.end(), s.dist_func_int, s.dist_func_int + nv);
+            L.mcdf_off = (uint32_t)H.distdata.size(); H.distdata.insert(H.distdata.end(), s.marg_cdf, s.marg_cdf + nv + 1);
+            H.inf_lights.push_back(i);
+        } else if (s.kind != PTRS_LIGHT_POINT && s.kind != PTRS_LIGHT_DIRECTIONAL) { err = "unknown light kind"; return PTRS_ERR_UNSUPPORTED; }
+    }
+    // ---- accelerator ----------------------------------------------------------------------------
+    std::vector<uint32_t> order;
+    if (d.bvh_nodes && d.n_bvh_nodes) {
+        if (!d.bvh_prims) return bad("bvh_nodes without bvh_prims");
+        static_assert(sizeof(PtrsBvhNode) == sizeof(DNode), "node layouts must agree");
+        H.nodes.resize(d.n_bvh_nodes);
+        std::memcpy(H.nodes.data(), d.bvh_nodes, sizeof(DNode) * d.n_bvh_nodes);
+        order.assign(d.bvh_prims, d.bvh_prims + n_tris);
+        for (auto &nd : H.nodes) { // validate indices so that a bad tree cannot fault the GPU
+            uint32_t np = nd.meta & 0xffffu;
+            if (np ? (nd.offset + np > n_tris) : (nd.offset >= d.n_bvh_nodes)) return bad("bvh node out of range");
+            if (!np && ((nd.meta >> 16) & 0xffu) > 2) return bad("bvh axis out of range");
+        }
+        for (uint32_t p : order) if (p >= n_tris) return bad("bvh prim out of range");
+        // depth by walking the depth-first layout
+        std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0, 1});
+        while (!st.empty()) { auto [i, dp] = st.back(); st.pop_back(); H.max_depth = std::max(H.max_depth, dp); const DNode &nd = H.nodes[i]; if (!(nd.meta & 0xffffu)) { if (i + 1 >= d.n_bvh_nodes || dp > 4096) return bad("bvh malformed"); st.push_back({i + 1, dp + 1}); st.push_back({nd.offset, dp + 1}); } }
+    } else if (n_tris) {
+        hostbvh::Builder B; B.nodes = &H.nodes; B.items.resize(n_tris);
+        for (size_t i = 0; i < n_tris; ++i) {
+            hostbvh::Item &it = B.items[i]; it.prim = (uint32_t)i; it.b = hostbvh::empty_box();
+            const DTriShade &T = H.shade[i];
+            hostbvh::grow_pt(it.b, T.p0); hostbvh::grow_pt(it.b, T.p1); hostbvh::grow_pt(it.b, T.p2);
+            for (int k = 0; k < 3; ++k) it.c[k] = it.b.lo[k] + 0.5f * (it.b.hi[k] - it.b.lo[k]);
+        }
+        H.nodes.reserve(2 * n_tris);
+        B.build(0, n_tris, 1);
+        if (B.overflow) return bad("leaf with more than 65535 coincident triangles");
+        order.swap(B.order);
+        H.max_depth = B.max_depth;
+        for (auto &nd : H.nodes) if ((nd.meta & 0xffffu) == 0 && (nd.meta >> 16) > 2) return bad("internal: bad axis");
+    }
+    H.tris.resize(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        const DTriShade &T = H.shade[order[k]]; DTri &t = H.tris[k];
+        t.p0[0] = T.p0[0]; t.p0[1] = T.p0[1]; t.p0[2] = T.p0[2]; t.p1x = T.p1[0]; t.p1y = T.p1[1]; t.p1z = T.p1[2];
+        t.p2x = T.p2[0]; t.p2y = T.p2[1]; t.p2z = T.p2[2]; t.prim = order[k]; t.flags = T.flags; t.alpha_tex = T.alpha_tex;
+    }
+    return PTRS_OK;
+}
+
+} // namespace pt

@@ -1,0 +1,293 @@
+// pt_items.h -- the per-path work of every wavefront stage, as plain functions of a path slot.
+//
+// The pipeline restates PathIntegrator::li (src/pathtracer/integrator.rs:392-503) as a loop over
+// stages; one loop iteration of the reference = one pass through
+//     extend (trace) -> sort -> shade -> connect (trace shadow, trace MIS) -> resolve
+// with path state in HBM between stages.  The functions below do the arithmetic; the HIP kernels
+// in kernels.hip (and, for CPU debugging only, tests/host_twin) wrap them with the queue logic.
+//   generate_item : integrator.rs:571-577 + sobol.rs:81-120 + pathtracer/mod.rs:59-81 + ray.rs:30-35
+//   sort_item     : integrator.rs:418-431 (emission, miss, depth cut) + material bucket
+//   shade_item    : integrator.rs:433-499, uniform_sample_one_light 192-217, estimate_direct 23-135
+//                   up to (not including) the two scene queries
+//   resolve_item  : estimate_direct's use of the query results (66-78, 121-134) and `l += ld` (444-446)
+//   film_item     : FilmTile::add_sample (film.rs:60-106) turned into a per-pixel gather
+#pragma once
+#include "pt_bvh.h"
+#include "pt_light.h"
+#include "pt_sobol.h"
+
+namespace pt {
+
+struct CamRay { f3 o, d, rx_d, ry_d; };
+
+// Camera::generate_ray_differential (pathtracer/mod.rs:59-81) followed by
+// scale_differentials(1/sqrt(spp)) (ray.rs:30-35).  rx_origin == ry_origin == o.
+PT_HD CamRay camera_ray(const DCamera &C, f2 pf, float diff_scale) {
+    const float *m = C.r2s;
+    f3 s = mk3(m[0] * pf.x + m[1] * pf.y + m[2] * 0.0f + m[3], m[4] * pf.x + m[5] * pf.y + m[6] * 0.0f + m[7], m[8] * pf.x + m[9] * pf.y + m[10] * 0.0f + m[11]);
+    float inv_denom = C.m23 / (s.z + C.m22); // Perspective3::unproject_point
+    f3 pc = mk3(s.x * inv_denom / C.m00, s.y * inv_denom / C.m11, -inv_denom);
+    CamRay r;
+    r.o = quat_rotate(C.rot, splat3(0.0f)) + ld3(C.trans);
+    f3 wd = quat_rotate(C.rot, pc);
+    r.d = normalize(wd);
+    f3 rxd = normalize(quat_rotate(C.rot, pc + ld3(C.dxc)));
+    f3 ryd = normalize(quat_rotate(C.rot, pc + ld3(C.dyc)));
+    r.rx_d = r.d + (rxd - r.d) * diff_scale;
+    r.ry_d = r.d + (ryd - r.d) * diff_scale;
+    return r;
+}
+
+struct PathCoord { int32_t sx, sy, px, py; uint32_t s; };
+PT_HD PathCoord path_coord(const DParams &R, const DSampler &S, uint32_t pid) {
+    const uint32_t npix = (uint32_t)(R.row1 - R.row0) * (uint32_t)R.NX;
+    uint32_t pl = pid % npix;
+    PathCoord c;
+    c.s = R.s0 + pid / npix;
+    c.sx = (int32_t)(pl % (uint32_t)R.NX);
+    c.sy = R.row0 + (int32_t)(pl / (uint32_t)R.NX);
+    c.px = S.min_x + c.sx; c.py = S.min_y + c.sy;
+    return c;
+}
+
+PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, const DPaths &P, uint32_t pid) {
+    PathCoord c = path_coord(R, S, pid);
+    SamplerState ss;
+    ss.index = sobol_index(S, (uint64_t)c.s, (uint32_t)c.sx, (uint32_t)c.sy);
+    ss.dim = 0; ss.scramble = pixel_scramble(c.px, c.py); ss.px = c.px; ss.py = c.py;
+    f2 u = get_2d(S, ss);
+    f2 pf = mk2((float)c.px + u.x, (float)c.py + u.y);
+    CamRay r = camera_ray(C, pf, R.inv_sqrt_spp);
+    P.ray_o[pid] = mkv4(r.o, PT_INF);
+    P.ray_d[pid] = mkv4(r.d, 0.0f);
+    P.beta[pid] = mkv4(splat3(1.0f), 1.0f);
+    P.L[pid] = mkv4(splat3(0.0f), 0.0f);
+    u4 st; st.x = (uint32_t)ss.index; st.y = (uint32_t)(ss.index >> 32); st.z = ss.dim | ST_HAS_DIFF; st.w = 0;
+    P.st[pid] = st;
+    P.pfilm[pid] = mkv4(mk3(pf.x, pf.y, 0.0f), 0.0f);
+}
+
+PT_HD int32_t st_bounces(uint32_t z) { return (int32_t)(int16_t)(z >> ST_BOUNCE_SHIFT); }
+PT_HD uint32_t st_pack(uint32_t dim, uint32_t flags, int32_t bounces) { return (dim & ST_DIM_MASK) | flags | ((uint32_t)(uint16_t)(int16_t)bounces << ST_BOUNCE_SHIFT); }
+
+// effective material kind for bucketing (NormalMaterial defers to the material it wraps)
+PT_HD int material_bucket(const DScene &sc, int32_t mat) {
+    DMaterial m = sc.mats[mat];
+    for (int g = 0; g < 4 && m.kind == 6; ++g) m = sc.mats[m.inner];
+    return m.kind;
+}
+
+// returns the material bucket (0..6) when the path goes on to shading, -1 when it ends here
+PT_HD int sort_item(const DParams &R, const DScene &sc, const DPaths &P, uint32_t pid) {
+    u4 st = P.st[pid];
+    u4 h = P.hit[pid];
+    const int32_t prim = (int32_t)h.x;
+    const int32_t bounces = st_bounces(st.z);
+    if (bounces == 0 || (st.z & ST_SPECULAR)) {
+        if (prim >= 0) {
+            const DTriShade &T = sc.shade[prim];
+            if (T.light >= 0) {
+                f3 d = xyz(P.ray_d[pid]);
+                Surface s = tri_surface(T, prim, u2f(h.y), u2f(h.z), u2f(h.w), -d);
+                f3 le = surface_le(sc, T, s, -d);
+                v4 Lv = P.L[pid];
+                f3 L = xyz(Lv) + xyz(P.beta[pid]) * le;
+                P.L[pid] = mkv4(L, Lv.w);
+            }
+        } else if (sc.n_inf > 0) {
+            f3 d = xyz(P.ray_d[pid]);
+            v4 Lv = P.L[pid];
+            f3 L = xyz(Lv), beta = xyz(P.beta[pid]);
+            for (uint32_t i = 0; i < sc.n_inf; ++i) L = L + beta * light_le(sc, sc.lights[sc.inf_lights[i]], d);
+            P.L[pid] = mkv4(L, Lv.w);
+        }
+    }
+    if (prim < 0 || bounces >= R.max_depth) return -1;
+    return material_bucket(sc, sc.shade[prim].material);
+}
+
+struct ShadeResult { bool next; bool nee; bool shadow; bool mis; };
+
+PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid) {
+    ShadeResult out; out.next = false; out.nee = false; out.shadow = false; out.mis = false;
+    const f3 ro = xyz(P.ray_o[pid]);
+    const f3 rd = xyz(P.ray_d[pid]);
+    v4 bv = P.beta[pid];
+    f3 beta = xyz(bv);
+    float eta_scale = bv.w;
+    u4 stv = P.st[pid];
+    u4 h = P.hit[pid];
+    const int32_t prim = (int32_t)h.x;
+    const DTriShade &T = sc.shade[prim];
+    int32_t bounces = st_bounces(stv.z);
+    PathCoord c = path_coord(R, S, pid);
+    SamplerState ss;
+    ss.index = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
+    ss.dim = stv.z & ST_DIM_MASK; ss.scramble = pixel_scramble(c.px, c.py); ss.px = c.px; ss.py = c.py;
+
+    const f3 wo = -rd;
+    Surface s = tri_surface(T, prim, u2f(h.y), u2f(h.z), u2f(h.w), wo);
+    if (stv.z & ST_HAS_DIFF) { // only the camera ray carries differentials (Q9)
+        v4 pf = P.pfilm[pid];
+        CamRay cr = camera_ray(C, mk2(pf.x, pf.y), R.inv_sqrt_spp);
+        surface_differentials(s, ro, cr.rx_d, ro, cr.ry_d);
+    }
+    Bsdf bsdf;
+    if (!make_bsdf(sc, T.material, s, bsdf)) { // integrator.rs:434-439 (Q7)
+        f3 o2 = spawn_origin(s.p, s.p_error, s.n, rd);
+        P.ray_o[pid] = mkv4(o2, PT_INF);
+        stv.z = st_pack(ss.dim, stv.z & ST_SPECULAR, bounces - 1);
+        P.st[pid] = stv;
+        out.next = true;
+        return out;
+    }
+
+    // ---- direct lighting: uniform_sample_one_light + estimate_direct up to the scene queries ----
+    const uint32_t NS = BSDF_ALL & ~BSDF_SPECULAR;
+    if (bsdf_num(bsdf, NS) > 0 && sc.n_lights > 0) {
+        f2 u_light = get_2d(S, ss);
+        f2 u_scat = get_2d(S, ss);
+        float fl = floor_(get_1d(S, ss) * (float)sc.n_lights);
+        uint32_t li = fl > 0.0f ? (uint32_t)fl : 0u;
+        if (li > sc.n_lights - 1u) li = sc.n_lights - 1u;
+        const DLight &Lt = sc.lights[li];
+        const bool delta = light_is_delta(Lt);
+        LightSample ls;
+        light_sample_li(sc, Lt, s.p, s.p_error, s.n, u_light, ls);
+        f3 A = splat3(0.0f);
+        float spdf = 0.0f;
+        f3 wi = ls.wi;
+        if (ls.pdf > 0.0f && !is_black(ls.li)) {
+            f3 f = bsdf_f(bsdf, wo, wi, NS) * fabs_(dot(wi, s.ns));
+            spdf = bsdf_pdf(bsdf, wo, wi, NS);
+            if (!is_black(f)) {
+                // VisibilityTester::unoccluded -> spawn_ray_to_it (interaction.rs:50-60, Q13)
+                f3 origin = offset_ray_origin(s.p, s.p_error, s.n, ls.p1 - s.p);
+                f3 target = offset_ray_origin(ls.p1, ls.p1_err, ls.p1_n, origin - ls.p1);
+                P.sh_o[pid] = mkv4(origin, 1.0f - 0.0001f);
+                P.sh_d[pid] = mkv4(target - origin, 0.0f);
+                A = delta ? f * ls.li / ls.pdf : f * ls.li * power_heuristic(ls.pdf, spdf) / ls.pdf;
+                out.shadow = true;
+            }
+        }
+        f3 fB = splat3(0.0f); float wB = 1.0f;
+        if (!delta) {
+            uint32_t sampled = BSDF_ALL;
+            fB = bsdf_sample_f(bsdf, wo, wi, u_scat, spdf, NS, sampled);
+            fB = fB * fabs_(dot(wi, s.ns));
+            if (!is_black(fB) && spdf > 0.0f) {
+                bool ok = true;
+                if (!(sampled & BSDF_SPECULAR)) {
+                    float lpdf = light_pdf_li(sc, Lt, s.p, s.p_error, s.n, wi);
+                    if (lpdf == 0.0f) ok = false; // `return ld` (Q11)
+                    else wB = power_heuristic(spdf, lpdf);
+                }
+                if (ok) {
+                    P.mis_o[pid] = mkv4(spawn_origin(s.p, s.p_error, s.n, wi), PT_INF);
+                    P.mis_d[pid] = mkv4(wi, 0.0f);
+                    out.mis = true;
+                }
+            }
+        }
+        if (out.shadow || out.mis) {
+            out.nee = true;
+            P.nee0[pid] = mkv4(A, wB);
+            P.nee1[pid] = mkv4(fB, spdf);
+            u4 n2; n2.x = f2u(beta.x); n2.y = f2u(beta.y); n2.z = f2u(beta.z);
+            n2.w = li | ((out.shadow ? NEE_SHADOW : 0u) | (out.mis ? NEE_MIS : 0u)) << 24;
+            P.nee2[pid] = n2;
+        }
+    }
+
+    // ---- continuation: integrator.rs:449-499 ---------------------------------------------------
+    f3 wi = splat3(0.0f);
+    float pdf = 0.0f; uint32_t flags = 0;
+    f3 f = bsdf_sample_f(bsdf, wo, wi, get_2d(S, ss), pdf, BSDF_ALL, flags);
+    if (is_black(f) || pdf == 0.0f) return out;
+    beta = beta * (f * fabs_(dot(wi, s.ns)) / pdf);
+    const bool spec = (flags & BSDF_SPECULAR) != 0;
+    if (spec && (flags & BSDF_TRANSMISSION)) {
+        float eta = bsdf.eta;
+        eta_scale *= dot(wo, s.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
+    }
+    f3 o2 = spawn_origin(s.p, s.p_error, s.n, wi);
+    if (R.rr_enable) {
+        float mx = max_comp(beta * eta_scale);
+        if (mx < R.rr_threshold && bounces > R.rr_start_depth) {
+            float q = max_(0.05f, 1.0f - mx);
+            if (get_1d(S, ss) < q) return out;
+            beta = beta / (1.0f - q);
+        }
+    }
+    bounces += 1;
+    P.ray_o[pid] = mkv4(o2, PT_INF);
+    P.ray_d[pid] = mkv4(wi, 0.0f);
+    P.beta[pid] = mkv4(beta, eta_scale);
+    stv.z = st_pack(ss.dim, spec ? ST_SPECULAR : 0u, bounces);
+    P.st[pid] = stv;
+    out.next = true;
+    return out;
+}
+
+PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid) {
+    v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
+    u4 n2 = P.nee2[pid];
+    const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
+    const DLight &Lt = sc.lights[li];
+    f3 ld = splat3(0.0f);
+    if ((fl & NEE_SHADOW) && P.sh_res[pid] == 0u) ld = ld + xyz(n0);
+    if (fl & NEE_MIS) {
+        u4 h = P.mis_hit[pid];
+        f3 wi = xyz(P.mis_d[pid]);
+        f3 l2 = splat3(0.0f);
+        if ((int32_t)h.x >= 0) {
+            const DTriShade &T = sc.shade[(int32_t)h.x];
+            if (T.light == (int32_t)li) { // std::ptr::eq(light, isect_light) (Q11)
+                Surface s = tri_surface(T, (int32_t)h.x, u2f(h.y), u2f(h.z), u2f(h.w), -wi);
+                l2 = surface_le(sc, T, s, -wi);
+            }
+        } else l2 = light_le(sc, Lt, wi);
+        if (!is_black(l2)) ld = ld + xyz(n1) * l2 * splat3(1.0f) * n0.w / n1.w;
+    }
+    f3 beta = mk3(u2f(n2.x), u2f(n2.y), u2f(n2.z));
+    v4 Lv = P.L[pid];
+    f3 L = xyz(Lv) + beta * ((float)sc.n_lights * ld);
+    P.L[pid] = mkv4(L, Lv.w);
+}
+
+// film gather for one output pixel over the current pass.  table = 16x16 Gaussian filter table
+// (film.rs:133-144).  Sample-pixels are visited x-outer / y-inner, samples innermost, which is the
+// order of one reference tile (integrator.rs:567-611).
+PT_HD void film_item(const DParams &R, const DSampler &S, const DPaths &P, const float *table, v4 *film, int32_t x, int32_t y) {
+    const float radius = 2.0f, inv_r = 1.0f / radius;
+    v4 acc = film[(size_t)y * (size_t)R.W + (size_t)x];
+    const uint32_t npix = (uint32_t)(R.row1 - R.row0) * (uint32_t)R.NX;
+    const uint32_t ns = R.s1 - R.s0;
+    for (int32_t qx = x - 2; qx <= x + 2; ++qx) {
+        int32_t sx = qx - S.min_x;
+        if (sx < 0 || sx >= R.NX) continue;
+        for (int32_t qy = y - 2; qy <= y + 2; ++qy) {
+            int32_t sy = qy - S.min_y;
+            if (sy < R.row0 || sy >= R.row1) continue;
+            uint32_t base = (uint32_t)(sy - R.row0) * (uint32_t)R.NX + (uint32_t)sx;
+            for (uint32_t k = 0; k < ns; ++k) {
+                uint32_t pid = k * npix + base;
+                v4 pf = P.pfilm[pid];
+                float pdx = pf.x - 0.5f, pdy = pf.y - 0.5f;
+                int32_t p0x = (int32_t)ceil_(pdx - radius), p0y = (int32_t)ceil_(pdy - radius);
+                int32_t p1x = (int32_t)(floor_(pdx + radius) + 1.0f), p1y = (int32_t)(floor_(pdy + radius) + 1.0f);
+                if (x < p0x || x >= p1x || y < p0y || y >= p1y) continue;
+                float fx = fabs_(((float)x - pdx) * inv_r * 16.0f);
+                float fy = fabs_(((float)y - pdy) * inv_r * 16.0f);
+                int32_t ix = (int32_t)floor_(fx); if (ix > 15) ix = 15;
+                int32_t iy = (int32_t)floor_(fy); if (iy > 15) iy = 15;
+                float w = table[iy * 16 + ix];
+                v4 Lv = P.L[pid];
+                acc.x += Lv.x * w; acc.y += Lv.y * w; acc.z += Lv.z * w; acc.w += w;
+            }
+        }
+    }
+    film[(size_t)y * (size_t)R.W + (size_t)x] = acc;
+}
+
+} // namespace pt

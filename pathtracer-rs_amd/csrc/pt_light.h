@@ -1,0 +1,137 @@
+// pt_light.h -- the Light trait for the four light kinds: src/pathtracer/light.rs (PointLight
+// 86-150, DirectionalLight 152-229, DiffuseAreaLight 231-319, InfiniteAreaLight 321-503),
+// Triangle::{sample, pdf_at_point, area} (shape.rs:541-578, 62-72, 533-539),
+// Distribution1D/2D (sampling.rs:128-230).
+#pragma once
+#include "pt_material.h"
+
+namespace pt {
+
+struct LightSample {
+    f3 li;       // radiance towards the reference point
+    f3 wi;
+    float pdf;
+    // VisibilityTester end points (light.rs:33-43): p1 of the shadow segment
+    f3 p1, p1_err, p1_n;
+};
+
+// Triangle::sample (shape.rs:541-578): point, face-forwarded normal, error bound, uv
+PT_HD void tri_sample(const DTriShade &T, f2 u, f3 &p, f3 &n, f3 &perr, f2 &uv) {
+    float su0 = sqrt_(u.x);
+    float b0 = 1.0f - su0, b1 = u.y * su0;
+    f3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
+    float b2 = 1.0f - b0 - b1;
+    p = (b0 * p0) + (b1 * p1) + b2 * p2;
+    n = normalize(cross(p1 - p0, p2 - p0));
+    if (T.flags & TRI_HAS_NORMAL) {
+        f3 ns = (b0 * ld3(T.n0)) + (b1 * ld3(T.n1)) + b2 * ld3(T.n2);
+        n = face_forward(n, ns);
+    } else if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) n = n * -1.0f;
+    perr = gamma_err(6) * (abs3(b0 * p0) + abs3(b1 * p1) + abs3(b2 * p2));
+    uv = mk2(b0 * T.uv0[0] + b1 * T.uv1[0] + b2 * T.uv2[0], b0 * T.uv0[1] + b1 * T.uv1[1] + b2 * T.uv2[1]);
+}
+
+// Triangle::pdf_at_point (shape.rs:62-72): a single-triangle intersection from the offset origin
+PT_HD float tri_pdf_at_point(const DTriShade &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi) {
+    f3 o = spawn_origin(ref_p, ref_err, ref_n, wi);
+    TriHit h;
+    if (!tri_test(o, wi, PT_INF, ld3(T.p0), ld3(T.p1), ld3(T.p2), h)) return 0.0f;
+    if (T.flags & TRI_DEGENERATE) return 0.0f;
+    Surface s = tri_surface(T, 0, h.b0, h.b1, h.b2, -wi);
+    return len2(ref_p - s.p) / (fabs_(dot(s.n, -wi)) * area);
+}
+
+PT_HD f3 env_lookup(const DScene &sc, const DLight &L, f2 st) { return tex_lookup_width(sc, sc.texs[L.lmap_tex], st, 0.0f); }
+PT_HD float spherical_theta(f3 v) { return pt_acosf(clamp_(v.z, -1.0f, 1.0f)); }
+PT_HD float spherical_phi(f3 v) { float p = pt_atan2f(v.y, v.x); return p < 0.0f ? p + 2.0f * PT_PI : p; }
+
+// Distribution1D::sample_continuous (sampling.rs:159-182)
+PT_HD float dist1d_sample(const float *func, const float *cdf, float func_int, uint32_t n, float u, float &pdf, uint32_t &off) {
+    off = find_interval_cdf(cdf, n + 1, u);
+    float du = u - cdf[off];
+    if ((cdf[off + 1] - cdf[off]) > 0.0f) du /= cdf[off + 1] - cdf[off];
+    pdf = func_int > 0.0f ? func[off] / func_int : 0.0f;
+    return ((float)off + du) / (float)n;
+}
+
+// Light::sample_li.  Returns false when the reference leaves the visibility tester unset
+// (InfiniteAreaLight with map_pdf == 0, light.rs:411-413) -- the reference would panic there.
+PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f2 u, LightSample &o) {
+    o.p1_err = splat3(0.0f); o.p1_n = splat3(0.0f);
+    if (L.kind == 0) { // point
+        f3 pl = ld3(L.v);
+        o.wi = normalize(pl - ref_p); o.pdf = 1.0f; o.p1 = pl;
+        o.li = ld3(L.c) / len2(pl - ref_p);
+        return true;
+    }
+    if (L.kind == 1) { // directional
+        f3 w = ld3(L.v);
+        o.wi = w; o.pdf = 1.0f; o.p1 = ref_p + w * (2.0f * L.world_radius);
+        o.li = ld3(L.c);
+        return true;
+    }
+    if (L.kind == 2) { // diffuse area light on one triangle
+        const DTriShade &T = sc.shade[L.tri];
+        f3 p, n, perr; f2 uv;
+        tri_sample(T, u, p, n, perr, uv);
+        o.wi = normalize(p - ref_p);
+        o.pdf = tri_pdf_at_point(T, L.area, ref_p, ref_err, ref_n, o.wi);
+        o.p1 = p; o.p1_err = perr; o.p1_n = n;
+        f3 w = -o.wi;
+        o.li = dot(n, w) > 0.0f ? tex_eval(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f) : splat3(0.0f);
+        return true;
+    }
+    // infinite area light
+    const float *D = sc.distdata;
+    float pdf_v, pdf_u; uint32_t v, dummy;
+    float d1 = dist1d_sample(D + L.fint_off, D + L.mcdf_off, L.marg_int, (uint32_t)L.nv, u.y, pdf_v, v);
+    float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), D[L.fint_off + v], (uint32_t)L.nu, u.x, pdf_u, dummy);
+    float map_pdf = pdf_u * pdf_v;
+    if (map_pdf == 0.0f) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; }
+    float theta = d1 * PT_PI, phi = d0 * 2.0f * PT_PI;
+    float ct = pt_cosf(theta), st = pt_sinf(theta), sp = pt_sinf(phi), cp = pt_cosf(phi);
+    o.wi = xform_vec(L.l2w, mk3(st * cp, st * sp, ct));
+    o.pdf = st == 0.0f ? 0.0f : map_pdf / (2.0f * PT_PI * PT_PI * st);
+    o.p1 = ref_p + o.wi * (2.0f * L.world_radius);
+    o.li = env_lookup(sc, L, mk2(d0, d1));
+    return true;
+}
+
+PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f3 w) {
+    if (L.kind == 2) return tri_pdf_at_point(sc.shade[L.tri], L.area, ref_p, ref_err, ref_n, w);
+    if (L.kind == 3) {
+        f3 wi = xform_vec(L.w2l, w);
+        float theta = spherical_theta(wi), phi = spherical_phi(wi);
+        float st = pt_sinf(theta);
+        if (st == 0.0f) return 0.0f;
+        // Distribution2D::pdf (sampling.rs:223-229), saturating float->usize casts
+        float pu = phi * PT_INV_2PI, pv = theta * PT_INV_PI;
+        uint32_t nu = (uint32_t)L.nu, nv = (uint32_t)L.nv;
+        float fu = pu * (float)nu, fv = pv * (float)nv;
+        uint32_t iu = (fu > 0.0f) ? (fu >= 4294967040.0f ? 0xffffffffu : (uint32_t)fu) : 0u;
+        uint32_t iv = (fv > 0.0f) ? (fv >= 4294967040.0f ? 0xffffffffu : (uint32_t)fv) : 0u;
+        if (iu > nu - 1u) iu = nu - 1u;
+        if (iv > nv - 1u) iv = nv - 1u;
+        const float *D = sc.distdata;
+        return (D[L.func_off + (uint64_t)iv * nu + iu] / L.marg_int) / (2.0f * PT_PI * PT_PI * st);
+    }
+    return 0.0f;
+}
+
+// Light::le for a ray that escapes (light.rs:45-47, 488-498)
+PT_HD f3 light_le(const DScene &sc, const DLight &L, f3 d) {
+    if (L.kind != 3) return splat3(0.0f);
+    f3 w = normalize(xform_vec(L.w2l, d));
+    return env_lookup(sc, L, mk2(spherical_phi(w) * PT_INV_2PI, spherical_theta(w) * PT_INV_PI));
+}
+
+// SurfaceMediumInteraction::le (interaction.rs:297-303) + DiffuseAreaLight::l (light.rs:252-258)
+PT_HD f3 surface_le(const DScene &sc, const DTriShade &T, const Surface &s, f3 w) {
+    if (T.light < 0) return splat3(0.0f);
+    if (dot(s.n, w) > 0.0f) return tex_eval(sc, sc.lights[T.light].ke_tex, s);
+    return splat3(0.0f);
+}
+
+PT_HD bool light_is_delta(const DLight &L) { return L.kind == 0 || L.kind == 1; }
+
+} // namespace pt

@@ -1,0 +1,107 @@
+// pt_material.h -- Material::compute_scattering_functions for every material kind:
+// src/pathtracer/material/mod.rs (normal_mapping 39-79, Matte 143-167, Mirror 169-195, Glass
+// 197-256), metal.rs:49-94, substrate.rs:42-68, disney.rs:172-264.
+#pragma once
+#include "pt_bxdf.h"
+
+namespace pt {
+
+PT_HD float roughness_to_alpha(float roughness) { // microfacet.rs:118-127
+    roughness = max_(roughness, 1e-3f);
+    float x = pt_logf(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+PT_HD void set_tr(Lobe &l, float ax, float ay, bool disney) { l.ax = max_(ax, 0.001f); l.ay = max_(ay, 0.001f); l.disney_g = disney; }
+PT_HD Lobe blank_lobe(int kind) {
+    Lobe l; l.kind = kind; l.r = splat3(0.0f); l.t = splat3(0.0f); l.eta_a = 1.0f; l.eta_b = 1.0f; l.fresnel = FR_NOOP;
+    l.fa = splat3(0.0f); l.fb = splat3(0.0f); l.ax = 0.001f; l.ay = 0.001f; l.disney_g = false;
+    return l;
+}
+
+PT_HD void normal_mapping(const DScene &sc, int32_t tex, Surface &s) { // mod.rs:39-79
+    f3 c0 = s.s_dpdu, c1 = s.s_dpdv, c2 = s.ns;
+    f3 tn = normalize(tex_eval(sc, tex, s));
+    f3 v = mk3(c0.x * tn.x + c1.x * tn.y + c2.x * tn.z, c0.y * tn.x + c1.y * tn.y + c2.y * tn.z, c0.z * tn.x + c1.z * tn.y + c2.z * tn.z);
+    f3 ns = normalize(v);
+    f3 ss = s.s_dpdu;
+    f3 ts = cross(ss, ns);
+    if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+    else coordinate_system(ns, ss, ts);
+    s.ns = ns; s.s_dpdu = ss; s.s_dpdv = ts;
+}
+
+// returns false when the material yields no BSDF (glass with black r and t, Q17)
+PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, Bsdf &b) {
+    DMaterial m = sc.mats[mat_id];
+    // NormalMaterial wraps another material (at most a few levels deep in practice)
+    for (int guard = 0; guard < 4 && m.kind == 6; ++guard) {
+        normal_mapping(sc, m.tex[0], s);
+        m = sc.mats[m.inner];
+    }
+    switch (m.kind) {
+        case 0: { // Matte
+            bsdf_init(b, s, 1.0f);
+            Lobe l = blank_lobe(LOBE_LAMBERT); l.r = tex_eval(sc, m.tex[0], s);
+            b.lobe[b.n++] = l;
+            return true;
+        }
+        case 2: { // Mirror
+            bsdf_init(b, s, 1.0f);
+            Lobe l = blank_lobe(LOBE_SPEC_REFL); l.r = splat3(1.0f);
+            b.lobe[b.n++] = l;
+            return true;
+        }
+        case 3: { // Glass
+            float eta = tex_eval(sc, m.tex[2], s).x;
+            f3 r = tex_eval(sc, m.tex[0], s), t = tex_eval(sc, m.tex[1], s);
+            bsdf_init(b, s, eta);
+            if (is_black(r) && is_black(t)) return false;
+            Lobe l = blank_lobe(LOBE_FRESNEL_SPEC); l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta;
+            b.lobe[b.n++] = l;
+            return true;
+        }
+        case 1: { // Metal
+            bsdf_init(b, s, 1.0f);
+            float ur = m.tex[4] >= 0 ? tex_eval(sc, m.tex[4], s).x : tex_eval(sc, m.tex[3], s).x;
+            float vr = m.tex[5] >= 0 ? tex_eval(sc, m.tex[5], s).x : tex_eval(sc, m.tex[3], s).x;
+            if (m.flags & 1) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+            Lobe l = blank_lobe(LOBE_MICRO_REFL); l.r = tex_eval(sc, m.tex[2], s);
+            set_tr(l, ur, vr, false);
+            l.fresnel = FR_CONDUCTOR; l.fa = tex_eval(sc, m.tex[0], s); l.fb = tex_eval(sc, m.tex[1], s);
+            b.lobe[b.n++] = l;
+            return true;
+        }
+        case 5: { // Substrate
+            bsdf_init(b, s, 1.0f);
+            f3 d = tex_eval(sc, m.tex[0], s), sp = tex_eval(sc, m.tex[1], s);
+            float ru = tex_eval(sc, m.tex[2], s).x, rv = tex_eval(sc, m.tex[3], s).x;
+            if (!is_black(d) || is_black(sp)) { // Q20
+                if (m.flags & 1) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
+                Lobe l = blank_lobe(LOBE_FRESNEL_BLEND); l.r = d; l.t = sp; set_tr(l, ru, rv, false);
+                b.lobe[b.n++] = l;
+            }
+            return true;
+        }
+        default: { // Disney
+            bsdf_init(b, s, 1.0f);
+            f3 c = tex_eval(sc, m.tex[0], s);
+            float metallic = tex_eval(sc, m.tex[1], s).x, e = tex_eval(sc, m.tex[2], s).x;
+            float strans = 0.0f;
+            float diffuse_weight = (1.0f - metallic) * (1.0f - strans);
+            float rough = tex_eval(sc, m.tex[3], s).x;
+            float lum = luminance(c);
+            f3 c_tint = lum > 0.0f ? c / lum : splat3(1.0f);
+            if (diffuse_weight > 0.0f) { Lobe l = blank_lobe(LOBE_DISNEY_DIFFUSE); l.r = diffuse_weight * c; b.lobe[b.n++] = l; }
+            float aspect = 1.0f;
+            float ax = max_(0.001f, (rough * rough) / aspect), ay = max_(0.001f, (rough * rough) * aspect);
+            float r0s = ((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f)); // schlick_r0_from_eta
+            f3 spec0 = lerp3(r0s * lerp3(splat3(1.0f), c_tint, 0.0f), c, metallic);
+            Lobe l = blank_lobe(LOBE_MICRO_REFL); l.r = splat3(1.0f); set_tr(l, ax, ay, true);
+            l.fresnel = FR_DISNEY; l.fa = spec0; l.fb = mk3(metallic, e, 0.0f);
+            b.lobe[b.n++] = l;
+            return true;
+        }
+    }
+}
+
+} // namespace pt

@@ -1,0 +1,169 @@
+// pt_render.h -- orchestration of PathIntegrator::render (src/pathtracer/integrator.rs:536-642)
+// as a wavefront pipeline, independent of where the stages execute.
+//
+// The reference walks 16x16 tiles with rayon; here the unit of scheduling is a *pass*: a block of
+// sample rows x a block of sample indices, whose paths are all in flight at once (sized to use
+// HBM generously: ~300 bytes of state per path).  Within a pass the reference's per-path loop
+// (integrator.rs:406-500) becomes `max_depth + 1` rounds of
+//     trace(extension) -> sort -> shade[material] -> trace(shadow) -> trace(MIS) -> resolve
+// and the film is updated once per pass by a deterministic gather.  The sampler ignores the tile
+// seed (sobol.rs:75-77), so the decomposition does not change any sample value (Q3).
+//
+// `BE` is the execution back end: the HIP back end (ptrs_hip.hip) launches gfx950 kernels; the
+// test-only host twin (tests/host_twin) runs the same stage functions serially on the CPU.
+#pragma once
+#include <chrono>
+#include <cmath>
+
+#include "pt_host_scene.h"
+#include "pt_items.h"
+
+namespace pt {
+
+struct SobolTablesHost {
+    std::vector<uint32_t> matrices;
+    std::vector<uint64_t> vdc, vdc_inv;
+    uint32_t stride = 52;
+    bool ok = false;
+};
+
+inline bool load_sobol_tables(const char *path, SobolTablesHost &T) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    char magic[8]; uint32_t hdr[6]; uint32_t lens[52];
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTRSSOB1", 8) == 0 && std::fread(hdr, 4, 6, f) == 6 && hdr[0] == 1024 && hdr[1] == 52;
+    if (ok) {
+        T.stride = hdr[4];
+        T.matrices.resize(1024u * 52u); T.vdc.resize((size_t)hdr[2] * T.stride); T.vdc_inv.resize((size_t)hdr[3] * T.stride);
+        ok = std::fread(T.matrices.data(), 4, T.matrices.size(), f) == T.matrices.size() && std::fread(lens, 4, 52, f) == 52 &&
+             std::fread(T.vdc.data(), 8, T.vdc.size(), f) == T.vdc.size() && std::fread(T.vdc_inv.data(), 8, T.vdc_inv.size(), f) == T.vdc_inv.size();
+    }
+    std::fclose(f);
+    T.ok = ok;
+    return ok;
+}
+
+inline int32_t round_up_pow2_i32(int32_t v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
+inline int64_t round_up_pow2_i64(int64_t v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v |= v >> 32; return v + 1; }
+
+// Film::new filter table with GuassianFilter::new(2.0) (film.rs:133-144, filter.rs:61-90)
+inline void gaussian_filter_table(float *t256) {
+    const float alpha = 2.0f, radius = 2.0f;
+    const float expv = pt_expf(-alpha * radius * radius);
+    int off = 0;
+    for (int y = 0; y < 16; ++y)
+        for (int x = 0; x < 16; ++x) {
+            float px = ((float)x + 0.5f) * radius / 16.0f, py = ((float)y + 0.5f) * radius / 16.0f;
+            float gx = max_(0.0f, pt_expf(-alpha * px * px) - expv), gy = max_(0.0f, pt_expf(-alpha * py * py) - expv);
+            t256[off++] = gx * gy;
+        }
+}
+
+struct SampleGrid { int32_t min_x, min_y, NX, NY; uint32_t spp; uint32_t log2_res; int32_t resolution; };
+
+// Film::get_sample_bounds (film.rs:174-185) + SobolSamplerBuilder::new (sobol.rs:35-60)
+inline SampleGrid make_sample_grid(int32_t W, int32_t H, int32_t spp_in) {
+    SampleGrid g;
+    const float r = 2.0f;
+    g.min_x = (int32_t)std::floor(0.5f - r); g.min_y = (int32_t)std::floor(0.5f - r);
+    int32_t max_x = (int32_t)std::ceil((float)W - 0.5f + r), max_y = (int32_t)std::ceil((float)H - 0.5f + r);
+    g.NX = max_x - g.min_x; g.NY = max_y - g.min_y;
+    g.spp = (uint32_t)round_up_pow2_i64((int64_t)(spp_in < 1 ? 1 : spp_in));
+    g.resolution = round_up_pow2_i32(g.NX > g.NY ? g.NX : g.NY);
+    g.log2_res = 31u - (uint32_t)__builtin_clz((uint32_t)g.resolution);
+    return g;
+}
+
+struct PassPlan { int32_t row0, row1; uint32_t s0, s1; };
+
+template <class BE>
+int render_impl(BE &be, const DScene &sc, const bool kinds_present[7], uint32_t bvh_depth, const PtrsCamera &cam, const PtrsRenderParams &prm,
+                v4 *film /* backend memory, W*H */, float *samples_out /* backend memory or null */, PtrsStats *stats, std::string &err) {
+    using clock = std::chrono::steady_clock;
+    auto t_begin = clock::now();
+    if (prm.width <= 0 || prm.height <= 0 || prm.spp <= 0 || prm.max_depth < 0) { err = "bad render parameters"; return PTRS_ERR_INVALID; }
+    if (bvh_depth > 64) { err = "BVH deeper than the 64-entry traversal stack (accelerator.rs:370)"; return PTRS_ERR_UNSUPPORTED; }
+    const SampleGrid g = make_sample_grid(prm.width, prm.height, prm.spp);
+    if (g.log2_res < 1 || g.log2_res > 25 || 2u * g.log2_res + (31u - (uint32_t)__builtin_clz(g.spp)) > 62u) { err = "resolution / spp outside the Sobol index range"; return PTRS_ERR_UNSUPPORTED; }
+    int32_t rb = prm.row_begin, re = prm.row_end;
+    if (re <= rb) { rb = 0; re = prm.height; }
+    if (rb < 0 || re > prm.height) { err = "row band outside the film"; return PTRS_ERR_INVALID; }
+    // sample rows (grid coordinates) whose footprint can touch output rows [rb, re)
+    const int32_t srow0 = std::max(rb, 0), srow1 = std::min(re + 4, g.NY);
+
+    DSampler S;
+    S.matrices = be.sobol_matrices(); S.vdc = be.sobol_vdc(g.log2_res - 1); S.vdc_inv = be.sobol_vdc_inv(g.log2_res - 1);
+    S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
+    DCamera C;
+    std::memcpy(C.rot, cam.rot, 16); std::memcpy(C.trans, cam.trans, 12);
+    C.m00 = cam.m00; C.m11 = cam.m11; C.m22 = cam.m22; C.m23 = cam.m23;
+    std::memcpy(C.r2s, cam.raster_to_screen, 64); std::memcpy(C.dxc, cam.dx_camera, 12); std::memcpy(C.dyc, cam.dy_camera, 12);
+    DParams R;
+    std::memset(&R, 0, sizeof(R));
+    R.max_depth = prm.max_depth; R.rr_threshold = prm.rr_threshold; R.rr_start_depth = prm.rr_start_depth; R.rr_enable = prm.rr_enable;
+    R.NX = g.NX; R.NY = g.NY; R.W = prm.width; R.H = prm.height;
+    R.inv_sqrt_spp = 1.0f / std::sqrt((float)g.spp);
+    R.counters_on = (prm.flags & PTRS_FLAG_COUNTERS) ? 1u : 0u;
+
+    // ---- pass planning ----------------------------------------------------------------------
+    uint64_t capacity = prm.paths_per_pass ? prm.paths_per_pass : (1ull << 24);
+    if (capacity < (uint64_t)g.NX) capacity = (uint64_t)g.NX;
+    const uint64_t band_rows = (uint64_t)(srow1 - srow0);
+    uint64_t rows_per_pass, samples_per_pass;
+    if (band_rows * (uint64_t)g.NX <= capacity) { rows_per_pass = band_rows; samples_per_pass = std::max<uint64_t>(1, std::min<uint64_t>(g.spp, capacity / (band_rows * (uint64_t)g.NX))); }
+    else { rows_per_pass = std::max<uint64_t>(1, capacity / (uint64_t)g.NX); samples_per_pass = 1; }
+    const uint64_t max_paths = rows_per_pass * (uint64_t)g.NX * samples_per_pass;
+    if (max_paths >= 0xffffffffull) { err = "pass too large"; return PTRS_ERR_INVALID; }
+
+    const uint32_t fixed_iters = (uint32_t)prm.max_depth + 1u; // li() runs at most max_depth+1 scene queries (Q7)
+    const uint32_t max_iters = fixed_iters + 64u;              // head-room for null-BSDF skips (bounces -= 1)
+    int rc = be.begin(sc, S, C, (uint32_t)max_paths, max_iters + 1u, bvh_depth, prm.flags, err);
+    if (rc != PTRS_OK) return rc;
+
+    PtrsStats st;
+    std::memset(&st, 0, sizeof(st));
+    std::vector<uint32_t> counts((size_t)(max_iters + 1u) * Q_STRIDE);
+    for (int32_t r0 = srow0; r0 < srow1; r0 += (int32_t)rows_per_pass) {
+        const int32_t r1 = std::min<int32_t>(srow1, r0 + (int32_t)rows_per_pass);
+        for (uint32_t s0 = 0; s0 < g.spp; s0 += (uint32_t)samples_per_pass) {
+            const uint32_t s1 = (uint32_t)std::min<uint64_t>(g.spp, (uint64_t)s0 + samples_per_pass);
+            R.row0 = r0; R.row1 = r1; R.s0 = s0; R.s1 = s1;
+            R.n_paths = (uint32_t)(r1 - r0) * (uint32_t)g.NX * (s1 - s0);
+            be.pass_begin(R);
+            be.generate();
+            uint32_t it = 0;
+            auto round = [&](uint32_t i) {
+                be.trace_extension(i);
+                be.sort(i);
+                for (int k = 0; k < 7; ++k) if (kinds_present[k]) be.shade(i, k);
+                be.trace_shadow(i);
+                be.trace_mis(i);
+                be.resolve(i);
+            };
+            for (; it < fixed_iters; ++it) round(it);
+            // A path can outlive max_depth+1 rounds only through null-BSDF skips (`bounces -= 1`,
+            // integrator.rs:434-439), which only glass can produce: poll the queue in that case.
+            if (kinds_present[PTRS_MAT_GLASS])
+                while (it < max_iters && be.read_count(it, Q_EXT) != 0) { round(it); ++it; }
+            // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
+            const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);
+            if (y1 > y0) be.film(film, y0, y1);
+            if (samples_out) be.export_samples(samples_out);
+            be.read_counts(counts.data(), it + 1u);
+            for (uint32_t i = 0; i <= it && i < max_iters + 1u; ++i) {
+                st.rays_extension += counts[(size_t)i * Q_STRIDE + Q_EXT];
+                st.rays_shadow += counts[(size_t)i * Q_STRIDE + Q_SHADOW];
+                st.rays_mis += counts[(size_t)i * Q_STRIDE + Q_MIS];
+            }
+            st.samples += R.n_paths;
+            st.passes += 1;
+        }
+    }
+    be.end(st);
+    st.bvh_nodes = sc.n_nodes; st.bvh_max_depth = bvh_depth;
+    st.ms_total = std::chrono::duration<double, std::milli>(clock::now() - t_begin).count();
+    if (stats) *stats = st;
+    return PTRS_OK;
+}
+
+} // namespace pt

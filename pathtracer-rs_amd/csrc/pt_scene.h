@@ -1,0 +1,155 @@
+// pt_scene.h -- device-resident scene, sampler, camera and path-state layouts (all POD).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   nodes   : 32-byte BVH nodes, depth-first (first child = i+1), two 16-byte loads per node.
+//   tris    : 48-byte leaf-ordered triangle records (3 x 16-byte loads, no index indirection).
+//   shade   : 160-byte per-triangle shading records (positions, normals, uvs, tangents, ids).
+//   paths   : structure-of-arrays of 16-byte vectors indexed by path slot; queues of slot ids.
+#pragma once
+#include "pt_vec.h"
+
+namespace pt {
+
+struct alignas(16) DNode { // = PtrsBvhNode = LinearBVHNode (accelerator.rs:89-95)
+    float pmin[3];
+    float pmax0; // pmax.x
+    float pmax1, pmax2;
+    uint32_t offset;    // leaf: first triangle record; interior: second child
+    uint32_t meta;      // num_prims (low 16 bits) | axis << 16
+};
+
+enum : uint32_t { TRI_HAS_NORMAL = 1, TRI_HAS_TANGENT = 2, TRI_REVERSE = 8, TRI_SWAPS = 16, TRI_DEGENERATE = 32, TRI_HAS_ALPHA = 64 };
+
+struct alignas(16) DTri { // leaf order
+    float p0[3]; float p1x;
+    float p1y, p1z; float p2x, p2y;
+    float p2z; uint32_t prim; uint32_t flags; int32_t alpha_tex;
+};
+
+struct alignas(16) DTriShade { // indexed by global triangle id (mesh-major)
+    float p0[3], p1[3], p2[3];
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float s0[3], s1[3], s2[3];
+    int32_t material;
+    int32_t light; // index into lights[] or -1 (GeometricPrimitive::area_light)
+    uint32_t flags;
+    int32_t alpha_tex;
+    uint32_t pad[3];
+};
+static_assert(sizeof(DNode) == 32, "node");
+static_assert(sizeof(DTri) == 48, "tri");
+static_assert(sizeof(DTriShade) == 160, "trishade");
+
+struct DMaterial { int32_t kind; int32_t tex[6]; int32_t flags; int32_t inner; };
+struct DTexLevel { uint64_t offset; int32_t cols, rows; };
+struct DTexture {
+    int32_t kind, channels;
+    float value[3], value2[3];
+    float su, sv, du, dv;
+    int32_t wrap, n_levels;
+    uint32_t first_level; uint32_t pad;
+};
+struct DLight {
+    int32_t kind;
+    float v[3], c[3];
+    int32_t tri, ke_tex;
+    float area, world_radius;
+    int32_t lmap_tex;
+    float l2w[12], w2l[12];
+    int32_t nu, nv;
+    uint32_t func_off, cdf_off, fint_off, mcdf_off;
+    float marg_int;
+};
+
+struct DScene {
+    const DNode *nodes;
+    const DTri *tris;
+    const DTriShade *shade;
+    const DMaterial *mats;
+    const DTexture *texs;
+    const DTexLevel *levels;
+    const float *texdata;
+    const DLight *lights;
+    const float *distdata;
+    const uint32_t *inf_lights;
+    uint32_t n_nodes, n_prims, n_lights, n_inf;
+};
+
+struct DSampler { // SobolSamplerBuilder::new (sobol.rs:35-60) + table rows
+    const uint32_t *matrices; // [1024*52]
+    const uint64_t *vdc;      // row m-1 of VD_C_SOBOL_MATRICES
+    const uint64_t *vdc_inv;  // row m-1 of VD_C_SOBOL_MATRICES_INV
+    uint32_t log2_res;
+    int32_t resolution;
+    int32_t min_x, min_y; // sample bounds p_min
+    uint32_t spp;         // power of two
+};
+
+struct DCamera { // = PtrsCamera
+    float rot[4], trans[3];
+    float m00, m11, m22, m23;
+    float r2s[16];
+    float dxc[3], dyc[3];
+};
+
+struct DParams {
+    int32_t max_depth;
+    float rr_threshold;
+    int32_t rr_start_depth, rr_enable;
+    int32_t NX, NY;        // sample-bounds extent (W+4, H+4)
+    int32_t W, H;          // film resolution
+    float inv_sqrt_spp;    // 1 / sqrt(spp as f32)
+    // current pass: sample rows [row0,row1) of the sample grid, samples [s0,s1)
+    int32_t row0, row1;
+    uint32_t s0, s1;
+    uint32_t n_paths;      // (row1-row0)*NX*(s1-s0)
+    uint32_t counters_on;
+};
+
+struct alignas(16) v4 { float x, y, z, w; };
+struct alignas(16) u4 { uint32_t x, y, z, w; };
+
+// path-state bits (u4.z of `st`)
+enum : uint32_t { ST_DIM_MASK = 0xfffu, ST_SPECULAR = 1u << 12, ST_HAS_DIFF = 1u << 13, ST_BOUNCE_SHIFT = 16 };
+// nee flags (stored in nee2.w as bits)
+enum : uint32_t { NEE_SHADOW = 1u, NEE_MIS = 2u };
+
+struct DPaths {
+    v4 *ray_o;  // o.xyz, (unused)
+    v4 *ray_d;  // d.xyz, (unused)
+    v4 *beta;   // beta.rgb, eta_scale
+    v4 *L;      // L.rgb, (unused)
+    u4 *st;     // sobol index lo, hi, state bits, (unused)
+    u4 *hit;    // prim (int), b0, b1, b2 (float bits)
+    v4 *pfilm;  // p_film.xy, (unused) -- written by generate, read by the film kernel
+    v4 *nee0;   // A.rgb (light-sampling term, final if unoccluded), weight of the BSDF term
+    v4 *nee1;   // f.rgb of the BSDF term (already times |wi.ns|), scattering pdf
+    u4 *nee2;   // beta at the vertex (rgb bits), light index | flags << 24
+    v4 *sh_o;   // shadow ray o.xyz, t_max
+    v4 *sh_d;   // shadow ray d.xyz
+    v4 *mis_o;  // MIS ray o.xyz
+    v4 *mis_d;  // MIS ray d.xyz
+    u4 *mis_hit;
+    uint32_t *sh_res; // 1 = occluded
+};
+
+// queue counters: one row of uint32 per loop iteration
+enum { Q_EXT = 0, Q_SHADOW = 1, Q_MIS = 2, Q_NEE = 3, Q_MAT0 = 4, Q_NUM_MAT = 7, Q_STRIDE = 16 };
+enum { CNT_EXT = 0, CNT_SHADOW = 1, CNT_MIS = 2, CNT_NODES = 3, CNT_TRIS = 4, CNT_NUM = 8 };
+
+struct DQueues {
+    uint32_t *ext[2];          // ping-pong extension-ray queues
+    uint32_t *mat[Q_NUM_MAT];  // one shade queue per material kind
+    uint32_t *shadow, *mis, *nee;
+    uint32_t *counts;          // [iters][Q_STRIDE]
+    unsigned long long *stats; // [CNT_NUM]
+};
+
+PT_HD uint32_t f2u(float f) { return ptf_bits(f); }
+PT_HD float u2f(uint32_t u) { return ptf_from_bits(u); }
+PT_HD v4 mkv4(f3 a, float w) { v4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = w; return r; }
+PT_HD f3 xyz(v4 a) { return mk3(a.x, a.y, a.z); }
+PT_HD f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+
+} // namespace pt

@@ -1,0 +1,68 @@
+// pt_sobol.h -- device Sobol' sampler: src/pathtracer/sampler/sobol.rs:81-193 and
+// lowdiscrepancy.rs:9-57 for a sampler with no sample arrays (array_end_dim == ARRAY_START_DIM == 5).
+#pragma once
+#include "pt_scene.h"
+
+namespace pt {
+
+// sobol_interval_to_index (lowdiscrepancy.rs:9-39); px,py relative to the sample bounds
+PT_HD uint64_t sobol_index(const DSampler &S, uint64_t frame, uint32_t px, uint32_t py) {
+    const uint32_t m = S.log2_res;
+    if (m == 0) return 0;
+    uint64_t index = frame << (m << 1);
+    uint64_t delta = 0;
+    for (uint32_t c = 0; frame != 0; frame >>= 1, ++c)
+        if (frame & 1) delta ^= S.vdc[c];
+    uint64_t b = ((uint64_t)(px << m) | (uint64_t)py) ^ delta;
+    for (uint32_t c = 0; b != 0; b >>= 1, ++c)
+        if (b & 1) index ^= S.vdc_inv[c];
+    return index;
+}
+
+// cantor_pairing(x + HALF_MAX, y + HALF_MAX) truncated to 32 bits (sobol.rs:83-86, math.rs:256-258)
+PT_HD uint32_t pixel_scramble(int32_t x, int32_t y) {
+    uint64_t a = (uint64_t)(int64_t)(x + 1073741823), b = (uint64_t)(int64_t)(y + 1073741823);
+    return (uint32_t)((a + b) * (a + b + 1) / 2 + b);
+}
+
+// sobol_sample (lowdiscrepancy.rs:42-57)
+PT_HD float sobol_sample(const DSampler &S, uint64_t index, uint32_t dim, uint32_t scramble) {
+    uint32_t v = scramble;
+    const uint32_t *mat = S.matrices + dim * 52u;
+    for (; index != 0; index >>= 1, ++mat)
+        if (index & 1) v ^= *mat;
+    return min_(PT_ONE_MINUS_EPS, (float)v * 0x1p-32f);
+}
+
+// sample_dimension (sobol.rs:177-193): dimensions 0/1 are mapped to the pixel and clamped (Q1)
+PT_HD float sample_dimension(const DSampler &S, uint64_t index, uint32_t dim, uint32_t scramble, int32_t px, int32_t py) {
+    float s = sobol_sample(S, index, dim, scramble);
+    if (dim < 2) {
+        s = s * (float)S.resolution + (float)(dim == 0 ? S.min_x : S.min_y);
+        s = clamp_(s - (float)(dim == 0 ? px : py), 0.0f, PT_ONE_MINUS_EPS);
+    }
+    return s;
+}
+
+// running sampler state of one path: index, dimension counter, pixel scramble
+struct SamplerState {
+    uint64_t index;
+    uint32_t dim;
+    uint32_t scramble;
+    int32_t px, py;
+};
+PT_HD float get_1d(const DSampler &S, SamplerState &st) { // sobol.rs:129-137 (the jump can never trigger)
+    float s = sample_dimension(S, st.index, st.dim, st.scramble, st.px, st.py);
+    st.dim += 1;
+    return s;
+}
+PT_HD f2 get_2d(const DSampler &S, SamplerState &st) { // sobol.rs:139-151: dimension 4 is skipped (Q2)
+    if (st.dim == 4) st.dim = 5;
+    f2 r;
+    r.x = sample_dimension(S, st.index, st.dim, st.scramble, st.px, st.py);
+    r.y = sample_dimension(S, st.index, st.dim + 1, st.scramble, st.px, st.py);
+    st.dim += 2;
+    return r;
+}
+
+} // namespace pt

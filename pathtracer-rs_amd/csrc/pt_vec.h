@@ -1,0 +1,144 @@
+// pt_vec.h -- scalar / vector substrate of the device code (gfx950) and of its host twin.
+//
+// Everything on the hot path is binary32 arithmetic in a fixed order with no FMA contraction
+// (-ffp-contract=off), IEEE division and sqrt, and the transcendental stand-ins of
+// include/ptrs_detmath.h, so results are bit-identical between gfx950 and x86-64.
+// Reference semantics restated here: src/common/math.rs (gamma :8, max_dimension :12-26,
+// coordinate_system :48-61, next_float_up/down :71-105, offset_ray_origin :107-131,
+// power_heuristic :167-171, find_interval :186-202) and nalgebra 0.32.2 vector ops.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/ptrs_detmath.h"
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define PT_DEV __device__ inline
+#define PT_MEM __host__ __device__ inline
+#else
+#define PT_DEV static inline
+#define PT_MEM inline
+#endif
+
+namespace pt {
+
+#define PT_INF (__builtin_huge_valf())
+#define PT_PI 3.14159265358979323846f
+#define PT_INV_PI 0.318309886183790671537767526745028724f
+#define PT_PI_2 1.57079632679489661923132169163975144f
+#define PT_PI_4 0.785398163397448309615660845819875721f
+#define PT_INV_2PI (PT_INV_PI * 0.5f)
+#define PT_ONE_MINUS_EPS 0x1.fffffep-1f
+#define PT_MACH_EPS (1.1920929e-07f * 0.5f)
+
+PT_HD float gamma_err(int n) { return ((float)n * PT_MACH_EPS) / (1.0f - (float)n * PT_MACH_EPS); }
+PT_HD float fabs_(float x) { return __builtin_fabsf(x); }
+PT_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
+PT_HD float floor_(float x) { return __builtin_floorf(x); }
+PT_HD float ceil_(float x) { return __builtin_ceilf(x); }
+PT_HD bool isinf_(float x) { return (ptf_bits(x) & 0x7fffffffu) == 0x7f800000u; }
+PT_HD bool isnan_(float x) { return x != x; }
+// Rust f32::max / f32::min (a NaN operand is ignored) and f32::clamp
+PT_HD float max_(float a, float b) { return a != a ? b : (b != b ? a : (a > b ? a : b)); }
+PT_HD float min_(float a, float b) { return a != a ? b : (b != b ? a : (a < b ? a : b)); }
+PT_HD float clamp_(float x, float lo, float hi) { if (x < lo) x = lo; if (x > hi) x = hi; return x; }
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+PT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_HD f3 splat3(float s) { return mk3(s, s, s); }
+PT_HD f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+PT_HD float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+PT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_HD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+PT_HD f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+PT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PT_HD float len2(f3 a) { return dot(a, a); }
+PT_HD float len(f3 a) { return sqrt_(len2(a)); }
+PT_HD f3 normalize(f3 a) { return a / len(a); }
+PT_HD f3 abs3(f3 a) { return mk3(fabs_(a.x), fabs_(a.y), fabs_(a.z)); }
+PT_HD bool is_black(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+PT_HD float max_comp(f3 a) { return max_(max_(a.x, a.y), a.z); }
+PT_HD float luminance(f3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
+PT_HD f3 sqrt3(f3 a) { return mk3(sqrt_(a.x), sqrt_(a.y), sqrt_(a.z)); }
+PT_HD f3 add_scalar(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+PT_HD f3 lerp3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
+PT_HD f3 face_forward(f3 n, f3 v) { return dot(n, v) < 0.0f ? -n : n; }
+
+PT_HD int max_dimension(f3 v) { return v.x > v.y ? (v.x > v.z ? 0 : 2) : (v.y > v.z ? 1 : 2); }
+
+PT_HD void coordinate_system(f3 v1, f3 &v2, f3 &v3) {
+    if (fabs_(v1.x) > fabs_(v1.y)) v2 = mk3(-v1.z, 0.0f, v1.x) / sqrt_(v1.x * v1.x + v1.z * v1.z);
+    else v2 = mk3(0.0f, v1.z, -v1.y) / sqrt_(v1.y * v1.y + v1.z * v1.z);
+    v3 = cross(v1, v2);
+}
+
+PT_HD float next_float_up(float v) {
+    if (isinf_(v) && v > 0.0f) return v;
+    if (v == -0.0f) v = 0.0f;
+    uint32_t ui = ptf_bits(v);
+    ui = (v >= 0.0f) ? ui + 1u : ui - 1u;
+    return ptf_from_bits(ui);
+}
+// Reference quirk Q32 (math.rs:98-103): the increment/decrement branches are swapped relative to
+// PBRT; reproduced as is.
+PT_HD float next_float_down(float v) {
+    if (isinf_(v) && v < 0.0f) return v;
+    if (v == 0.0f) v = -0.0f;
+    uint32_t ui = ptf_bits(v);
+    ui = (v > 0.0f) ? ui + 1u : ui - 1u;
+    return ptf_from_bits(ui);
+}
+PT_HD float nudge(float po, float off) { return off > 0.0f ? next_float_up(po) : (off < 0.0f ? next_float_down(po) : po); }
+PT_HD f3 offset_ray_origin(f3 p, f3 p_error, f3 n, f3 w) {
+    float d = dot(abs3(n), p_error);
+    f3 off = d * n;
+    if (dot(w, n) < 0.0f) off = -off;
+    f3 po = p + off;
+    return mk3(nudge(po.x, off.x), nudge(po.y, off.y), nudge(po.z, off.z));
+}
+PT_HD float power_heuristic(float f_pdf, float g_pdf) { // nf = ng = 1 (1.0 * pdf is exact)
+    float f = 1.0f * f_pdf, g = 1.0f * g_pdf;
+    return (f * f) / (f * f + g * g);
+}
+PT_HD bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float &x0, float &x1) {
+    float det = a00 * a11 - a01 * a10;
+    if (fabs_(det) < 1e-10f) return false;
+    float r0 = (a11 * b0 - a01 * b1) / det;
+    float r1 = (a00 * b1 - a10 * b0) / det;
+    if (r0 != r0 || r1 != r1) return false;
+    x0 = r0; x1 = r1;
+    return true;
+}
+PT_HD int32_t abs_mod(int32_t a, int32_t b) { int32_t r = a - (a / b) * b; return r < 0 ? r + b : r; }
+// math.rs:186-202 on a cdf array: pred(i) = cdf[i] <= u
+PT_HD uint32_t find_interval_cdf(const float *cdf, uint32_t size, float u) {
+    uint32_t first = 0, n = size;
+    while (n > 0) {
+        uint32_t half = n >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; n -= half + 1; } else n = half;
+    }
+    uint32_t v = first - 1u; // wraps when first == 0 (Q27), then clamps to size-2
+    return v > size - 2u ? size - 2u : v;
+}
+// nalgebra UnitQuaternion(i,j,k,w) * Vector3
+PT_HD f3 quat_rotate(const float *q, f3 v) {
+    f3 qv = mk3(q[0], q[1], q[2]);
+    f3 t = cross(qv, v) * 2.0f;
+    f3 c = cross(qv, t);
+    return t * q[3] + c + v;
+}
+// row-major 3x4 affine (first 12 floats of a 4x4): Transform * Vector
+PT_HD f3 xform_vec(const float *m, f3 v) {
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+PT_HD f3 xform_pt(const float *m, f3 p) {
+    return mk3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+
+} // namespace pt

@@ -1,0 +1,529 @@
+// ptrs_hip.hip -- gfx950 (MI355X) kernels and the C ABI of include/ptrs.h.
+//
+// One wavefront stage = one kernel.  Every queue-driven kernel is launched with a fixed persistent
+// grid (CUs x 8 workgroups of 256 threads = 4 wave64 per workgroup) and grid-strides over a queue
+// whose length it reads from device memory, so a whole pass is enqueued without host round trips.
+// Queue compaction uses one wave-aggregated atomic per wave (64-bit ballot + mbcnt prefix).
+// The traversal stack lives in LDS, one 4-byte column per lane (bank = lane % 32: conflict free).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (bit-exact arithmetic, see pt_vec.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pt_render.h"
+
+using namespace pt;
+
+// ---- embedded Sobol' tables (generated from data/sobol_tables.bin by the build) -------------------
+static const unsigned char k_sobol_blob[] = {
+#include "sobol_tables_data.inc"
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                                             \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                   \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                            \
+            return PTRS_ERR_DEVICE;                                                                               \
+        }                                                                                                         \
+    } while (0)
+
+constexpr int BLOCK = 256;
+
+// ---- wave-aggregated queue push (wave64) ----------------------------------------------------------
+__device__ inline uint32_t wave_push(uint32_t *counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0xffffffffu;
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+struct LdsStack { // column `threadIdx.x` of a [depth][BLOCK] LDS array
+    uint32_t *col;
+    int n;
+    __device__ inline void push(uint32_t v) { col[n * BLOCK] = v; ++n; }
+    __device__ inline uint32_t pop() { --n; return col[n * BLOCK]; }
+    __device__ inline bool empty() const { return n == 0; }
+};
+
+// ---- kernels ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCamera C, DPaths P, uint32_t *ext0, uint32_t *count0) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < R.n_paths; pid += stride) {
+        generate_item(R, S, C, P, pid);
+        ext0[pid] = pid;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count0 = R.n_paths;
+}
+
+// Ray source: (ro, rd) indexed by path slot, ro.w = t_max.  ANY: write occl[pid]; else write hits[pid].
+template <bool ANY, int DEPTH>
+__global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ count,
+                                                 const v4 *__restrict__ ro, const v4 *__restrict__ rd, u4 *__restrict__ hits,
+                                                 uint32_t *__restrict__ occl, float *__restrict__ tout, unsigned long long *stats, uint32_t counters_on) {
+    __shared__ uint32_t lds_stack[DEPTH * BLOCK];
+    const uint32_t n = *count;
+    const uint32_t stride = gridDim.x * BLOCK;
+    uint32_t nn = 0, nt = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t pid = queue ? queue[i] : i;
+        const v4 o = ro[pid], d = rd[pid];
+        LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
+        HitRec h;
+        const bool hit = bvh_trace<ANY>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+        if (ANY) occl[pid] = hit ? 1u : 0u;
+        else { u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); hits[pid] = r; if (tout) tout[pid] = h.t; }
+    }
+    if (counters_on) { atomicAdd(&stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&stats[CNT_TRIS], (unsigned long long)nt); }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sort(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask) {
+    const uint32_t *queue = Q.ext[it & 1u];
+    uint32_t *counts = Q.counts + (size_t)it * Q_STRIDE;
+    const uint32_t n = counts[Q_EXT];
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t pid = queue[i];
+        const int k = sort_item(R, sc, P, pid);
+        for (int m = 0; m < Q_NUM_MAT; ++m) { // wavefront-ballot material bucketing
+            if (!(kinds_mask & (1u << m))) continue;
+            const uint32_t slot = wave_push(&counts[Q_MAT0 + m], k == m);
+            if (k == m) Q.mat[m][slot] = pid;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, int kind) {
+    const uint32_t *queue = Q.mat[kind];
+    uint32_t *counts = Q.counts + (size_t)it * Q_STRIDE;
+    uint32_t *next_count = Q.counts + (size_t)(it + 1u) * Q_STRIDE + Q_EXT;
+    uint32_t *next = Q.ext[(it + 1u) & 1u];
+    const uint32_t n = counts[Q_MAT0 + kind];
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t pid = queue[i];
+        const ShadeResult r = shade_item(R, S, C, sc, P, pid);
+        uint32_t slot = wave_push(next_count, r.next);
+        if (r.next) next[slot] = pid;
+        slot = wave_push(&counts[Q_SHADOW], r.shadow);
+        if (r.shadow) Q.shadow[slot] = pid;
+        slot = wave_push(&counts[Q_MIS], r.mis);
+        if (r.mis) Q.mis[slot] = pid;
+        slot = wave_push(&counts[Q_NEE], r.nee);
+        if (r.nee) Q.nee[slot] = pid;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues Q, uint32_t it) {
+    const uint32_t n = Q.counts[(size_t)it * Q_STRIDE + Q_NEE];
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) resolve_item(sc, P, Q.nee[i]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P, const float *__restrict__ table, v4 *film, int32_t y0, int32_t y1) {
+    __shared__ float tab[256];
+    tab[threadIdx.x] = table[threadIdx.x];
+    __syncthreads();
+    const uint32_t total = (uint32_t)(y1 - y0) * (uint32_t)R.W;
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += stride) {
+        const int32_t x = (int32_t)(i % (uint32_t)R.W), y = y0 + (int32_t)(i / (uint32_t)R.W);
+        film_item(R, S, P, tab, film, x, y);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_export_samples(DParams R, DSampler S, DPaths P, float *out) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < R.n_paths; pid += stride) {
+        const PathCoord c = path_coord(R, S, pid);
+        const size_t o = (((size_t)c.sy * (size_t)R.NX + (size_t)c.sx) * S.spp + c.s) * 3;
+        const v4 L = P.L[pid];
+        out[o] = L.x; out[o + 1] = L.y; out[o + 2] = L.z;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sobol(DSampler S, uint32_t n, const int32_t *px, const int32_t *py, const uint64_t *sn, const uint32_t *dims, float *out, uint64_t *idx_out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t idx = sobol_index(S, sn[i], (uint32_t)(px[i] - S.min_x), (uint32_t)(py[i] - S.min_y));
+    if (idx_out) idx_out[i] = idx;
+    out[i] = sample_dimension(S, idx, dims[i], pixel_scramble(px[i], py[i]), px[i], py[i]);
+}
+
+// ---- device buffers ---------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return PTRS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        HIPCHK(hipMalloc(&p, n));
+        bytes = n;
+        return PTRS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+template <class T> int upload(DevBuf &b, const std::vector<T> &v) {
+    size_t n = v.size() * sizeof(T);
+    int rc = b.ensure(n ? n : 16);
+    if (rc != PTRS_OK) return rc;
+    if (n) HIPCHK(hipMemcpy(b.p, v.data(), n, hipMemcpyHostToDevice));
+    return PTRS_OK;
+}
+
+struct SobolDevice { // one copy per device
+    int device = -1;
+    DevBuf matrices, vdc, vdc_inv;
+    uint32_t stride = 52;
+};
+std::mutex g_mu;
+std::vector<SobolDevice *> g_sobol;
+
+int get_sobol(int device, SobolDevice **out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto *s : g_sobol) if (s->device == device) { *out = s; return PTRS_OK; }
+    const unsigned char *b = k_sobol_blob;
+    if (sizeof(k_sobol_blob) < 32 || std::memcmp(b, "PTRSSOB1", 8) != 0) { g_err = "embedded sobol tables corrupt"; return PTRS_ERR_INVALID; }
+    uint32_t hdr[6]; std::memcpy(hdr, b + 8, 24);
+    const size_t nmat = (size_t)hdr[0] * hdr[1], stride = hdr[4];
+    const unsigned char *pm = b + 32, *pv = pm + nmat * 4 + 52 * 4, *pvi = pv + (size_t)hdr[2] * stride * 8;
+    auto *s = new SobolDevice(); s->device = device; s->stride = (uint32_t)stride;
+    int rc;
+    if ((rc = s->matrices.ensure(nmat * 4)) != PTRS_OK || (rc = s->vdc.ensure((size_t)hdr[2] * stride * 8)) != PTRS_OK || (rc = s->vdc_inv.ensure((size_t)hdr[3] * stride * 8)) != PTRS_OK) { delete s; return rc; }
+    HIPCHK(hipMemcpy(s->matrices.p, pm, nmat * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->vdc.p, pv, (size_t)hdr[2] * stride * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->vdc_inv.p, pvi, (size_t)hdr[3] * stride * 8, hipMemcpyHostToDevice));
+    g_sobol.push_back(s);
+    *out = s;
+    return PTRS_OK;
+}
+
+} // namespace
+
+struct PtrsScene {
+    int device = 0;
+    HostScene H; // host copy kept for validation / stats
+    DScene sc{};
+    DevBuf nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
+    // render workspace, grown on demand and reused across calls
+    DevBuf ws[32];
+    DevBuf counts, stats, table, film_tmp, samples_tmp;
+    std::vector<hipEvent_t> ev_pool;
+    int n_cu = 256;
+    ~PtrsScene() {
+        for (auto &b : {&nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &stats, &table, &film_tmp, &samples_tmp}) b->release();
+        for (auto &b : ws) b.release();
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+struct HipBackend {
+    PtrsScene *ps; hipStream_t stream; SobolDevice *sob;
+    DScene sc; DSampler S; DCamera C; DParams R; DPaths P; DQueues Q;
+    uint32_t cap = 0, rows = 0, depth = 0, flags = 0, kinds_mask = 0;
+    int grid_max = 2048;
+    int rc = PTRS_OK;
+    // timing
+    struct Span { int cat; hipEvent_t a, b; };
+    std::vector<Span> spans; size_t ev_next = 0;
+    uint64_t launches = 0, trace_launches = 0;
+
+    const uint32_t *sobol_matrices() { return (const uint32_t *)sob->matrices.p; }
+    const uint64_t *sobol_vdc(uint32_t row) { return (const uint64_t *)sob->vdc.p + (size_t)row * sob->stride; }
+    const uint64_t *sobol_vdc_inv(uint32_t row) { return (const uint64_t *)sob->vdc_inv.p + (size_t)row * sob->stride; }
+
+    hipEvent_t ev() {
+        if (ev_next == ps->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { rc = PTRS_ERR_DEVICE; return nullptr; } ps->ev_pool.push_back(e); }
+        return ps->ev_pool[ev_next++];
+    }
+    void t0(int cat) { if (flags & PTRS_FLAG_TIMING) { Span s; s.cat = cat; s.a = ev(); s.b = ev(); if (s.a) (void)hipEventRecord(s.a, stream); spans.push_back(s); } ++launches; if (cat == 0) ++trace_launches; }
+    void t1() { if (flags & PTRS_FLAG_TIMING) { if (spans.back().b) (void)hipEventRecord(spans.back().b, stream); } }
+    int grid_for(uint32_t n) const { uint32_t g = (n + BLOCK - 1) / BLOCK; if (g < 1) g = 1; return (int)(g > (uint32_t)grid_max ? (uint32_t)grid_max : g); }
+
+    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, std::string &err) {
+        sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_;
+        grid_max = ps->n_cu * 8;
+        for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
+        const size_t n16 = (size_t)cap * 16, n4 = (size_t)cap * 4;
+        void **slots16[] = {(void **)&P.ray_o, (void **)&P.ray_d, (void **)&P.beta, (void **)&P.L, (void **)&P.st, (void **)&P.hit, (void **)&P.pfilm, (void **)&P.nee0,
+                            (void **)&P.nee1, (void **)&P.nee2, (void **)&P.sh_o, (void **)&P.sh_d, (void **)&P.mis_o, (void **)&P.mis_d, (void **)&P.mis_hit};
+        int w = 0;
+        for (auto s : slots16) { if ((rc = ps->ws[w].ensure(n16)) != PTRS_OK) { err = g_err; return rc; } *s = ps->ws[w++].p; }
+        void **slots4[] = {(void **)&P.sh_res, (void **)&Q.ext[0], (void **)&Q.ext[1], (void **)&Q.shadow, (void **)&Q.mis, (void **)&Q.nee};
+        for (auto s : slots4) { if ((rc = ps->ws[w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } *s = ps->ws[w++].p; }
+        for (int k = 0; k < Q_NUM_MAT; ++k) {
+            Q.mat[k] = nullptr;
+            if (kinds_mask & (1u << k)) { if ((rc = ps->ws[w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } Q.mat[k] = (uint32_t *)ps->ws[w].p; }
+            ++w;
+        }
+        if ((rc = ps->counts.ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK || (rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
+        Q.counts = (uint32_t *)ps->counts.p; Q.stats = (unsigned long long *)ps->stats.p;
+        float tab[256]; gaussian_filter_table(tab);
+        if (hipMemcpyAsync(ps->table.p, tab, 1024, hipMemcpyHostToDevice, stream) != hipSuccess || hipMemsetAsync(Q.stats, 0, CNT_NUM * 8, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { err = "workspace initialisation failed"; return PTRS_ERR_DEVICE; }
+        return PTRS_OK;
+    }
+    void pass_begin(const DParams &R_) { R = R_; (void)hipMemsetAsync(Q.counts, 0, (size_t)rows * Q_STRIDE * 4, stream); }
+    void generate() { t0(1); hipLaunchKernelGGL(k_generate, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, C, P, Q.ext[0], Q.counts + Q_EXT); t1(); }
+
+    template <bool ANY> void launch_trace(const uint32_t *queue, const uint32_t *count, const v4 *ro, const v4 *rd, u4 *hits, uint32_t *occl, uint32_t n_upper) {
+        t0(0);
+        dim3 g(grid_for(n_upper)), b(BLOCK);
+        if (depth <= 16) hipLaunchKernelGGL((k_trace<ANY, 16>), g, b, 0, stream, sc, queue, count, ro, rd, hits, occl, (float *)nullptr, Q.stats, R.counters_on);
+        else if (depth <= 32) hipLaunchKernelGGL((k_trace<ANY, 32>), g, b, 0, stream, sc, queue, count, ro, rd, hits, occl, (float *)nullptr, Q.stats, R.counters_on);
+        else hipLaunchKernelGGL((k_trace<ANY, 64>), g, b, 0, stream, sc, queue, count, ro, rd, hits, occl, (float *)nullptr, Q.stats, R.counters_on);
+        t1();
+    }
+    uint32_t *cnt(uint32_t it, int q) { return Q.counts + (size_t)it * Q_STRIDE + q; }
+    void trace_extension(uint32_t it) { launch_trace<false>(Q.ext[it & 1u], cnt(it, Q_EXT), P.ray_o, P.ray_d, P.hit, nullptr, R.n_paths); }
+    void trace_shadow(uint32_t it) { launch_trace<true>(Q.shadow, cnt(it, Q_SHADOW), P.sh_o, P.sh_d, nullptr, P.sh_res, R.n_paths); }
+    void trace_mis(uint32_t it) { launch_trace<false>(Q.mis, cnt(it, Q_MIS), P.mis_o, P.mis_d, P.mis_hit, nullptr, R.n_paths); }
+    void sort(uint32_t it) { t0(1); hipLaunchKernelGGL(k_sort, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, sc, P, Q, it, kinds_mask); t1(); }
+    void shade(uint32_t it, int kind) { t0(1); hipLaunchKernelGGL(k_shade, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, C, sc, P, Q, it, kind); t1(); }
+    void resolve(uint32_t it) { t0(1); hipLaunchKernelGGL(k_resolve, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, sc, P, Q, it); t1(); }
+    uint32_t read_count(uint32_t it, int q) { uint32_t v = 0; (void)hipMemcpyAsync(&v, cnt(it, q), 4, hipMemcpyDeviceToHost, stream); (void)hipStreamSynchronize(stream); return v; }
+    void read_counts(uint32_t *dst, uint32_t n_rows) { (void)hipMemcpyAsync(dst, Q.counts, (size_t)n_rows * Q_STRIDE * 4, hipMemcpyDeviceToHost, stream); if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE; }
+    void film(v4 *film_px, int32_t y0, int32_t y1) { t0(2); hipLaunchKernelGGL(k_film, dim3(grid_for((uint32_t)(y1 - y0) * (uint32_t)R.W)), dim3(BLOCK), 0, stream, R, S, P, (const float *)ps->table.p, film_px, y0, y1); t1(); }
+    void export_samples(float *out) { t0(2); hipLaunchKernelGGL(k_export_samples, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, P, out); t1(); }
+    void end(PtrsStats &st) {
+        if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE;
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { g_err = std::string("kernel launch failed: ") + hipGetErrorString(le); rc = PTRS_ERR_DEVICE; }
+        unsigned long long hs[CNT_NUM] = {0};
+        (void)hipMemcpy(hs, Q.stats, sizeof(hs), hipMemcpyDeviceToHost);
+        st.nodes_visited = hs[CNT_NODES]; st.tris_tested = hs[CNT_TRIS];
+        st.kernel_launches = launches; st.trace_launches = trace_launches;
+        for (auto &s : spans) {
+            float ms = 0.0f;
+            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.cat == 0) st.ms_trace += ms; else if (s.cat == 1) st.ms_shade += ms; else st.ms_film += ms; }
+        }
+        size_t bytes = 0;
+        for (auto &b : ps->ws) bytes += b.bytes;
+        st.device_bytes = bytes + ps->counts.bytes + ps->film_tmp.bytes + ps->samples_tmp.bytes;
+    }
+};
+
+int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm, v4 *film_dev, float *samples_dev, hipStream_t stream, PtrsStats *stats) {
+    if (!ps || !cam || !prm || !film_dev) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    HIPCHK(hipSetDevice(ps->device));
+    HipBackend be;
+    be.ps = ps; be.stream = stream;
+    int rc = get_sobol(ps->device, &be.sob);
+    if (rc != PTRS_OK) return rc;
+    std::string err;
+    rc = render_impl(be, ps->sc, ps->H.kinds_present, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err);
+    if (rc != PTRS_OK) { if (!err.empty()) g_err = err; return rc; }
+    if (be.rc != PTRS_OK) { if (g_err.empty()) g_err = "device error during render"; return be.rc; }
+    return PTRS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ptrs_abi_version(void) { return PTRS_ABI_VERSION; }
+const char *ptrs_last_error(void) { return g_err.c_str(); }
+
+// struct sizes as compiled, for the binding self-check (tests/test_abi.py)
+int ptrs_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(PtrsTexture); case 1: return (int)sizeof(PtrsMaterial); case 2: return (int)sizeof(PtrsMesh);
+        case 3: return (int)sizeof(PtrsLight); case 4: return (int)sizeof(PtrsBvhNode); case 5: return (int)sizeof(PtrsSceneDesc);
+        case 6: return (int)sizeof(PtrsCamera); case 7: return (int)sizeof(PtrsRenderParams); case 8: return (int)sizeof(PtrsStats);
+        case 9: return (int)sizeof(PtrsHit); case 10: return (int)sizeof(PtrsFilmPixel);
+        default: return -1;
+    }
+}
+
+int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out) {
+    if (!desc || !out) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (this library has no CPU fallback)"; return PTRS_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { g_err = "device ordinal out of range"; return PTRS_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    PtrsScene *ps = new PtrsScene();
+    ps->device = device;
+    int rc = build_host_scene(*desc, ps->H, g_err);
+    if (rc != PTRS_OK) { delete ps; return rc; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ps->n_cu = prop.multiProcessorCount;
+    HostScene &H = ps->H;
+    if ((rc = upload(ps->nodes, H.nodes)) || (rc = upload(ps->tris, H.tris)) || (rc = upload(ps->shade, H.shade)) || (rc = upload(ps->mats, H.mats)) ||
+        (rc = upload(ps->texs, H.texs)) || (rc = upload(ps->levels, H.levels)) || (rc = upload(ps->texdata, H.texdata)) || (rc = upload(ps->lights, H.lights)) ||
+        (rc = upload(ps->distdata, H.distdata)) || (rc = upload(ps->inf, H.inf_lights))) { delete ps; return rc; }
+    DScene &sc = ps->sc;
+    sc.nodes = (const DNode *)ps->nodes.p; sc.tris = (const DTri *)ps->tris.p; sc.shade = (const DTriShade *)ps->shade.p; sc.mats = (const DMaterial *)ps->mats.p;
+    sc.texs = (const DTexture *)ps->texs.p; sc.levels = (const DTexLevel *)ps->levels.p; sc.texdata = (const float *)ps->texdata.p; sc.lights = (const DLight *)ps->lights.p;
+    sc.distdata = (const float *)ps->distdata.p; sc.inf_lights = (const uint32_t *)ps->inf.p;
+    sc.n_nodes = (uint32_t)H.nodes.size(); sc.n_prims = (uint32_t)H.tris.size(); sc.n_lights = (uint32_t)H.lights.size(); sc.n_inf = (uint32_t)H.inf_lights.size();
+    *out = ps;
+    return PTRS_OK;
+}
+
+void ptrs_scene_destroy(PtrsScene *scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    delete scene;
+}
+
+int ptrs_scene_info(PtrsScene *scene, uint64_t *n_nodes, uint64_t *max_depth, uint64_t *n_tris) {
+    if (!scene) { g_err = "null scene"; return PTRS_ERR_INVALID; }
+    if (n_nodes) *n_nodes = scene->H.nodes.size();
+    if (max_depth) *max_depth = scene->H.max_depth;
+    if (n_tris) *n_tris = scene->H.tris.size();
+    return PTRS_OK;
+}
+
+int ptrs_render_device(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, void *film_inout_device, void *hip_stream, PtrsStats *stats) {
+    return do_render(scene, camera, params, (v4 *)film_inout_device, nullptr, (hipStream_t)hip_stream, stats);
+}
+
+int ptrs_render_samples(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, float *sample_rgb, PtrsStats *stats) {
+    if (!scene || !params || !film_inout) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    HIPCHK(hipSetDevice(scene->device));
+    const size_t npx = (size_t)params->width * (size_t)params->height;
+    int rc = scene->film_tmp.ensure(npx * sizeof(PtrsFilmPixel));
+    if (rc != PTRS_OK) return rc;
+    HIPCHK(hipMemcpy(scene->film_tmp.p, film_inout, npx * sizeof(PtrsFilmPixel), hipMemcpyHostToDevice));
+    float *sdev = nullptr; size_t sbytes = 0;
+    if (sample_rgb) {
+        const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
+        sbytes = (size_t)g.NX * (size_t)g.NY * (size_t)g.spp * 3 * sizeof(float);
+        if ((rc = scene->samples_tmp.ensure(sbytes)) != PTRS_OK) return rc;
+        HIPCHK(hipMemset(scene->samples_tmp.p, 0, sbytes));
+        sdev = (float *)scene->samples_tmp.p;
+    }
+    rc = do_render(scene, camera, params, (v4 *)scene->film_tmp.p, sdev, nullptr, stats);
+    if (rc != PTRS_OK) return rc;
+    HIPCHK(hipMemcpy(film_inout, scene->film_tmp.p, npx * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost));
+    if (sample_rgb) HIPCHK(hipMemcpy(sample_rgb, sdev, sbytes, hipMemcpyDeviceToHost));
+    return PTRS_OK;
+}
+
+int ptrs_render(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, PtrsStats *stats) {
+    return ptrs_render_samples(scene, camera, params, film_inout, nullptr, stats);
+}
+
+int ptrs_render_single_pixel(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, int32_t px, int32_t py, float *rgb_out) {
+    // render_single_pixel (integrator.rs:505-534): run the one film row that holds the pixel and
+    // return that pixel's per-sample radiance.  Pixels in the filter apron outside the film rows
+    // are not reachable through a row band and are rejected.
+    if (!scene || !params || !rgb_out) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    if (px < -2 || px >= params->width + 2 || py < 0 || py >= params->height) { g_err = "pixel outside the film rows"; return PTRS_ERR_INVALID; }
+    const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
+    std::vector<PtrsFilmPixel> film((size_t)params->width * params->height);
+    std::memset(film.data(), 0, film.size() * sizeof(PtrsFilmPixel));
+    std::vector<float> samples((size_t)g.NX * g.NY * g.spp * 3);
+    PtrsRenderParams p = *params;
+    p.row_begin = py; p.row_end = py + 1;
+    int rc = ptrs_render_samples(scene, camera, &p, film.data(), samples.data(), nullptr);
+    if (rc != PTRS_OK) return rc;
+    const size_t o = (((size_t)(py - g.min_y) * g.NX + (size_t)(px - g.min_x)) * g.spp) * 3;
+    std::memcpy(rgb_out, samples.data() + o, (size_t)g.spp * 3 * sizeof(float));
+    return PTRS_OK;
+}
+
+int ptrs_trace_rays(PtrsScene *scene, uint32_t n, const float *rays, int32_t any_hit, PtrsHit *hits_out, PtrsStats *stats) {
+    if (!scene || (n && (!rays || !hits_out))) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    if (scene->H.max_depth > 64) { g_err = "BVH deeper than 64"; return PTRS_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(scene->device));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return PTRS_OK;
+    std::vector<v4> ro(n), rd(n);
+    for (uint32_t i = 0; i < n; ++i) { ro[i].x = rays[7 * i]; ro[i].y = rays[7 * i + 1]; ro[i].z = rays[7 * i + 2]; ro[i].w = rays[7 * i + 6]; rd[i].x = rays[7 * i + 3]; rd[i].y = rays[7 * i + 4]; rd[i].z = rays[7 * i + 5]; rd[i].w = 0.0f; }
+    DevBuf bo, bd, bh, bc, bs, bt;
+    int rc;
+    if ((rc = upload(bo, ro)) || (rc = upload(bd, rd)) || (rc = bh.ensure((size_t)n * 16)) || (rc = bc.ensure(16)) || (rc = bs.ensure(CNT_NUM * 8)) || (rc = bt.ensure((size_t)n * 4))) { bo.release(); bd.release(); bh.release(); bc.release(); bs.release(); bt.release(); return rc; }
+    hipError_t e = hipMemcpy(bc.p, &n, 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(bs.p, 0, CNT_NUM * 8);
+    const uint32_t depth = scene->H.max_depth;
+    dim3 g((n + BLOCK - 1) / BLOCK > 2048u ? 2048u : (n + BLOCK - 1) / BLOCK), b(BLOCK);
+    hipEvent_t ea, eb; (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+    (void)hipEventRecord(ea, nullptr);
+#define LAUNCH_T(ANYV)                                                                                                                                  \
+    do {                                                                                                                                                \
+        if (depth <= 16) hipLaunchKernelGGL((k_trace<ANYV, 16>), g, b, 0, nullptr, scene->sc, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
+        else if (depth <= 32) hipLaunchKernelGGL((k_trace<ANYV, 32>), g, b, 0, nullptr, scene->sc, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
+        else hipLaunchKernelGGL((k_trace<ANYV, 64>), g, b, 0, nullptr, scene->sc, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
+    } while (0)
+    if (any_hit) LAUNCH_T(true); else LAUNCH_T(false);
+#undef LAUNCH_T
+    (void)hipEventRecord(eb, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0.0f; (void)hipEventElapsedTime(&ms, ea, eb);
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    if (e == hipSuccess) {
+        if (any_hit) {
+            std::vector<uint32_t> oc(n);
+            e = hipMemcpy(oc.data(), bh.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+            for (uint32_t i = 0; i < n; ++i) { hits_out[i].prim = oc[i] ? 0 : -1; hits_out[i].t = rays[7 * i + 6]; hits_out[i].b0 = hits_out[i].b1 = hits_out[i].b2 = 0.0f; }
+        } else {
+            std::vector<u4> hh(n); std::vector<float> tt(n);
+            e = hipMemcpy(hh.data(), bh.p, (size_t)n * 16, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(tt.data(), bt.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+            for (uint32_t i = 0; i < n; ++i) { hits_out[i].prim = (int32_t)hh[i].x; hits_out[i].b0 = u2f(hh[i].y); hits_out[i].b1 = u2f(hh[i].z); hits_out[i].b2 = u2f(hh[i].w); hits_out[i].t = tt[i]; }
+        }
+    }
+    if (e == hipSuccess && stats) {
+        unsigned long long hs[CNT_NUM];
+        e = hipMemcpy(hs, bs.p, sizeof(hs), hipMemcpyDeviceToHost);
+        stats->nodes_visited = hs[CNT_NODES]; stats->tris_tested = hs[CNT_TRIS]; stats->ms_trace = ms; stats->trace_launches = 1; stats->kernel_launches = 1;
+        if (any_hit) stats->rays_shadow = n; else stats->rays_extension = n;
+    }
+    bo.release(); bd.release(); bh.release(); bc.release(); bs.release(); bt.release();
+    if (e != hipSuccess) { g_err = std::string("ptrs_trace_rays: ") + hipGetErrorString(e); return PTRS_ERR_DEVICE; }
+    return PTRS_OK;
+}
+
+int ptrs_sobol_samples(const PtrsRenderParams *params, uint32_t n, const int32_t *px, const int32_t *py, const uint64_t *sample_nums, const uint32_t *dims, float *out, uint64_t *index_out) {
+    if (!params || (n && (!px || !py || !sample_nums || !dims || !out))) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (this library has no CPU fallback)"; return PTRS_ERR_DEVICE; }
+    HIPCHK(hipSetDevice(params->device));
+    if (n == 0) return PTRS_OK;
+    const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (dims[i] >= 1024u) { g_err = "sobol sampler can only sample up to 1024 dimensions"; return PTRS_ERR_INVALID; }
+        if (px[i] < g.min_x || px[i] >= g.min_x + g.NX || py[i] < g.min_y || py[i] >= g.min_y + g.NY) { g_err = "pixel outside the sample bounds"; return PTRS_ERR_INVALID; }
+    }
+    SobolDevice *sob;
+    int rc = get_sobol(params->device, &sob);
+    if (rc != PTRS_OK) return rc;
+    DSampler S;
+    S.matrices = (const uint32_t *)sob->matrices.p; S.vdc = (const uint64_t *)sob->vdc.p + (size_t)(g.log2_res - 1) * sob->stride; S.vdc_inv = (const uint64_t *)sob->vdc_inv.p + (size_t)(g.log2_res - 1) * sob->stride;
+    S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
+    DevBuf bx, by, bn, bdm, bo, bi;
+    auto cleanup = [&]() { bx.release(); by.release(); bn.release(); bdm.release(); bo.release(); bi.release(); };
+    if ((rc = bx.ensure((size_t)n * 4)) || (rc = by.ensure((size_t)n * 4)) || (rc = bn.ensure((size_t)n * 8)) || (rc = bdm.ensure((size_t)n * 4)) || (rc = bo.ensure((size_t)n * 4)) || (rc = bi.ensure((size_t)n * 8))) { cleanup(); return rc; }
+    hipError_t e = hipMemcpy(bx.p, px, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(by.p, py, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(bn.p, sample_nums, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(bdm.p, dims, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sobol, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, nullptr, S, n, (const int32_t *)bx.p, (const int32_t *)by.p, (const uint64_t *)bn.p, (const uint32_t *)bdm.p, (float *)bo.p, (uint64_t *)bi.p);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, bo.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && index_out) e = hipMemcpy(index_out, bi.p, (size_t)n * 8, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) { g_err = std::string("ptrs_sobol_samples: ") + hipGetErrorString(e); return PTRS_ERR_DEVICE; }
+    return PTRS_OK;
+}
+
+} // extern "C"

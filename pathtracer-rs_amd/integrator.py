@@ -1,0 +1,191 @@
+"""Host mirror of the reference's integrator API over the HIP library.
+
+Mirrors (reference file:line):
+  SamplerBuilder::new(log, spp, &sample_bounds)          src/pathtracer/sampler/sobol.rs:35-60
+  PathIntegrator::{new, preprocess, render,
+                   render_single_pixel}                  src/pathtracer/integrator.rs:230,250,536,505
+Construction matches src/main.rs:103-110:
+    integrator = PathIntegrator(SamplerBuilder(spp, camera.film.get_sample_bounds()), max_depth)
+    integrator.preprocess(scene); integrator.render(camera, scene)
+render() accumulates into camera.film like the reference (callers clear() first for a fresh image).
+"""
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class PtrsError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Loads libptrs_hip.so (built in-tree by build.py).  Fails loudly when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_HERE, "libptrs_hip.so")
+    if not os.path.exists(so):
+        raise PtrsError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                        "There is no CPU fallback for the render path." % so)
+    L = C.CDLL(so)
+    L.ptrs_last_error.restype = C.c_char_p
+    if L.ptrs_abi_version() != 1:
+        raise PtrsError("ABI version mismatch")
+    structs = [abi.PtrsTexture, abi.PtrsMaterial, abi.PtrsMesh, abi.PtrsLight, abi.PtrsBvhNode, abi.PtrsSceneDesc, abi.PtrsCamera,
+               abi.PtrsRenderParams, abi.PtrsStats, abi.PtrsHit]
+    for i, s in enumerate(structs):
+        if L.ptrs_abi_sizeof(i) != C.sizeof(s):
+            raise PtrsError("ABI struct %s: library %d bytes, binding %d bytes" % (s.__name__, L.ptrs_abi_sizeof(i), C.sizeof(s)))
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtrsError("ptrs error %d: %s" % (rc, load_library().ptrs_last_error().decode()))
+
+
+def round_up_pow2(v):
+    return 1 << max(0, (int(v) - 1).bit_length())
+
+
+class SamplerBuilder:
+    """SobolSamplerBuilder (sobol.rs:25-78): spp is rounded up to a power of two with a warning."""
+
+    def __init__(self, samples_per_pixel, sample_bounds):
+        self.samples_per_pixel = round_up_pow2(samples_per_pixel)
+        if self.samples_per_pixel != samples_per_pixel:
+            warnings.warn("non power-of-two sample count rounded up to %d for sobol sampler" % self.samples_per_pixel)
+        self.sample_bounds = tuple(sample_bounds)
+        ext = max(self.sample_bounds[2] - self.sample_bounds[0], self.sample_bounds[3] - self.sample_bounds[1])
+        self.resolution = round_up_pow2(ext)
+        self.log_2_resolution = self.resolution.bit_length() - 1
+
+    def with_seed(self, _seed):  # sobol.rs:75-77: a no-op in the reference as well
+        return self
+
+
+class _DeviceScene:
+    def __init__(self, render_scene, device=0, bvh=None):
+        self.handle = C.c_void_p()
+        self.device = device
+        desc = render_scene.desc(bvh)
+        _check(load_library().ptrs_scene_create(C.byref(desc), int(device), C.byref(self.handle)))
+
+    def info(self):
+        n, d, t = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(load_library().ptrs_scene_info(self.handle, C.byref(n), C.byref(d), C.byref(t)))
+        return dict(bvh_nodes=n.value, bvh_max_depth=d.value, n_tris=t.value)
+
+    def close(self):
+        if self.handle:
+            load_library().ptrs_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _device_scene(render_scene, device=0, bvh=None):
+    key = "_ptrs_dev_%d" % device
+    ds = getattr(render_scene, key, None)
+    if ds is None or bvh is not None:
+        ds = _DeviceScene(render_scene, device, bvh)
+        setattr(render_scene, key, ds)
+    return ds
+
+
+class PathIntegrator:
+    """PathIntegrator (integrator.rs:219-246): rr_threshold 1.0, rr_start_depth 3, rr_enable true."""
+
+    def __init__(self, sampler_builder, max_depth, show_progress_bar=False, device=0, paths_per_pass=0):
+        self.sampler_builder = sampler_builder
+        self.max_depth = int(max_depth)
+        self.rr_threshold, self.rr_start_depth, self.rr_enable = 1.0, 3, True
+        self.show_progress_bar = show_progress_bar
+        self.device = device
+        self.paths_per_pass = paths_per_pass
+        self.last_stats = None
+
+    def preprocess(self, scene):  # integrator.rs:250-258
+        if len(scene.lights) > 16:
+            warnings.warn("scene contains too many lights for path integrator to handle well")
+
+    def toggle_progress_bar(self):  # integrator.rs:260-262
+        self.show_progress_bar = not self.show_progress_bar
+
+    def params(self, camera, row_begin=0, row_end=0, flags=0):
+        p = abi.PtrsRenderParams()
+        p.width, p.height = camera.film.width, camera.film.height
+        p.spp, p.max_depth = self.sampler_builder.samples_per_pixel, self.max_depth
+        p.rr_threshold, p.rr_start_depth, p.rr_enable = self.rr_threshold, self.rr_start_depth, int(self.rr_enable)
+        p.row_begin, p.row_end = row_begin, (row_end if row_end else camera.film.height)
+        p.device, p.paths_per_pass, p.flags = self.device, self.paths_per_pass, flags
+        return p
+
+    def render(self, camera, scene, row_begin=0, row_end=0, flags=0, want_samples=False):
+        """integrator.rs:536-642 on the GPU; accumulates into camera.film.pixels (host memory)."""
+        ds = _device_scene(scene, self.device)
+        p = self.params(camera, row_begin, row_end, flags)
+        cam = camera.to_abi()
+        stats = abi.PtrsStats()
+        film = camera.film.pixels
+        samples = None
+        if want_samples:
+            samples = np.zeros((p.height + 4, p.width + 4, round_up_pow2(p.spp), 3), dtype=np.float32)
+        _check(load_library().ptrs_render_samples(ds.handle, C.byref(cam), C.byref(p), C.c_void_p(film.ctypes.data),
+                                                  C.c_void_p(samples.ctypes.data) if want_samples else None, C.byref(stats)))
+        self.last_stats = stats
+        return samples if want_samples else None
+
+    def render_device(self, camera, scene, film_device_ptr, stream=0, row_begin=0, row_end=0, flags=0):
+        """Same, film accumulators in device memory (film_device_ptr: width*height*16 bytes)."""
+        ds = _device_scene(scene, self.device)
+        p = self.params(camera, row_begin, row_end, flags)
+        cam = camera.to_abi()
+        stats = abi.PtrsStats()
+        _check(load_library().ptrs_render_device(ds.handle, C.byref(cam), C.byref(p), C.c_void_p(int(film_device_ptr)), C.c_void_p(int(stream)), C.byref(stats)))
+        self.last_stats = stats
+        return stats
+
+    def render_single_pixel(self, camera, pixel, scene):  # integrator.rs:505-534
+        ds = _device_scene(scene, self.device)
+        p = self.params(camera)
+        cam = camera.to_abi()
+        out = np.zeros((round_up_pow2(p.spp), 3), dtype=np.float32)
+        _check(load_library().ptrs_render_single_pixel(ds.handle, C.byref(cam), C.byref(p), int(pixel[0]), int(pixel[1]), C.c_void_p(out.ctypes.data)))
+        return out
+
+
+def trace_rays(scene, rays, any_hit=False, device=0, bvh=None):
+    """RenderScene::intersect / intersect_p (pathtracer/mod.rs:92-98) for a batch of rays
+    (n x 7: o, d, t_max) through the traversal kernel."""
+    ds = _device_scene(scene, device, bvh)
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
+    hits = np.zeros(rays.shape[0], dtype=abi.HIT_DTYPE)
+    stats = abi.PtrsStats()
+    _check(load_library().ptrs_trace_rays(ds.handle, rays.shape[0], C.c_void_p(rays.ctypes.data), int(any_hit), C.c_void_p(hits.ctypes.data), C.byref(stats)))
+    return hits, stats
+
+
+def sobol_samples(params, px, py, sample_nums, dims):
+    """SobolSampler::sample_dimension (sobol.rs:177-193) for arbitrary (pixel, sample, dimension)."""
+    px = np.ascontiguousarray(px, dtype=np.int32)
+    py = np.ascontiguousarray(py, dtype=np.int32)
+    sn = np.ascontiguousarray(sample_nums, dtype=np.uint64)
+    dm = np.ascontiguousarray(dims, dtype=np.uint32)
+    out = np.zeros(px.shape[0], dtype=np.float32)
+    idx = np.zeros(px.shape[0], dtype=np.uint64)
+    _check(load_library().ptrs_sobol_samples(C.byref(params), px.shape[0], C.c_void_p(px.ctypes.data), C.c_void_p(py.ctypes.data), C.c_void_p(sn.ctypes.data),
+                                             C.c_void_p(dm.ctypes.data), C.c_void_p(out.ctypes.data), C.c_void_p(idx.ctypes.data)))
+    return out, idx

@@ -1,0 +1,115 @@
+"""Procedural scenes (seeded, no assets): parity-test scenes and stand-ins for the glTF configs of
+BASELINE.json whose assets (Sponza, Classroom) are not available offline.  Geometry only uses the
+records of include/ptrs.h, so the same description feeds the HIP library and the oracle."""
+import math
+
+import numpy as np
+
+from . import abi
+from .scene import RenderScene, gen_cube, gen_rectangle, look_at_camera, transform_point, transform_vector
+
+
+def _trs(scale, translate, rot_y_deg=0.0):
+    c, s = math.cos(math.radians(rot_y_deg)), math.sin(math.radians(rot_y_deg))
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float32) * np.array(scale, dtype=np.float32)[None, :]
+    m[:3, 3] = translate
+    return m
+
+
+def _add(scene, gen, m, material, uv=None, emission=None):
+    pos, normal, idx = gen
+    wpos = np.array([transform_point(m, p) for p in pos], dtype=np.float32)
+    wn = np.array([transform_vector(m, n) for n in normal], dtype=np.float32)
+    return scene.add_mesh(wpos, idx, material, normal=wn, uv=uv, emission_rgb=emission)
+
+
+def uv_sphere(n_theta=12, n_phi=24):
+    """Latitude/longitude sphere with vertex normals and uvs (radius 1, centre 0)."""
+    pos, uv = [], []
+    for i in range(n_theta + 1):
+        th = math.pi * i / n_theta
+        for j in range(n_phi + 1):
+            ph = 2.0 * math.pi * j / n_phi
+            pos.append([math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph)])
+            uv.append([j / n_phi, i / n_theta])
+    idx = []
+    for i in range(n_theta):
+        for j in range(n_phi):
+            a, b = i * (n_phi + 1) + j, (i + 1) * (n_phi + 1) + j
+            if i > 0:
+                idx.append([a, a + 1, b])
+            if i < n_theta - 1:
+                idx.append([a + 1, b + 1, b])
+    pos = np.array(pos, dtype=np.float32)
+    return pos, pos.copy(), np.array(idx, dtype=np.uint32), np.array(uv, dtype=np.float32)
+
+
+def material_zoo(resolution=(96, 64), with_delta_lights=True):
+    """A closed room with one object per material kind, checker textures, an area light, a point
+    light and a directional light.  Exercises every BxDF / light code path of the hot path except
+    image textures and the environment light."""
+    s = RenderScene()
+    white = s.add_material(abi.MAT_MATTE, [s.const_rgb([0.7, 0.7, 0.7])])
+    checker = s.add_texture(kind=abi.TEX_CHECKER, channels=3, value=np.array([0.8, 0.2, 0.2], np.float32), value2=np.array([0.2, 0.2, 0.8], np.float32), su=4.0, sv=4.0, du=0.1, dv=0.2)
+    floor = s.add_material(abi.MAT_MATTE, [checker])
+    mirror = s.add_material(abi.MAT_MIRROR)
+    glass = s.add_material(abi.MAT_GLASS, [s.const_rgb([1, 1, 1]), s.const_rgb([0.9, 0.95, 1.0]), s.const_f(1.5)])
+    null_glass = s.add_material(abi.MAT_GLASS, [s.const_rgb([0, 0, 0]), s.const_rgb([0, 0, 0]), s.const_f(1.3)])
+    metal = s.add_material(abi.MAT_METAL, [s.const_rgb([0.2, 0.92, 1.1]), s.const_rgb([3.9, 2.45, 2.14]), s.const_rgb([1, 1, 1]), s.const_f(0.15), -1, -1], flags=0)
+    metal_aniso = s.add_material(abi.MAT_METAL, [s.const_rgb([0.14, 0.37, 1.44]), s.const_rgb([3.98, 2.38, 1.6]), s.const_rgb([0.9, 0.9, 0.9]), -1, s.const_f(0.3), s.const_f(0.05)], flags=1)
+    rough_tex = s.add_texture(kind=abi.TEX_CHECKER, channels=1, value=0.2, value2=0.6, su=3.0, sv=3.0)
+    disney = s.add_material(abi.MAT_DISNEY, [s.const_rgb([0.8, 0.5, 0.2]), s.const_f(0.3), s.const_f(1.5), rough_tex])
+    disney_metal = s.add_material(abi.MAT_DISNEY, [checker, s.const_f(1.0), s.const_f(1.5), s.const_f(0.25)])
+    substrate = s.add_material(abi.MAT_SUBSTRATE, [s.const_rgb([0.1, 0.5, 0.2]), s.const_rgb([0.04, 0.04, 0.04]), s.const_f(0.1), s.const_f(0.2)], flags=0)
+    rect, cube = gen_rectangle(), gen_cube()
+    uv_rect = np.array([[0, 0], [1, 0], [0, 1], [1, 1]], dtype=np.float32)
+    rx = lambda deg: np.array([[1, 0, 0, 0], [0, math.cos(math.radians(deg)), -math.sin(math.radians(deg)), 0], [0, math.sin(math.radians(deg)), math.cos(math.radians(deg)), 0], [0, 0, 0, 1]], dtype=np.float32)
+    rz = lambda deg: np.array([[math.cos(math.radians(deg)), -math.sin(math.radians(deg)), 0, 0], [math.sin(math.radians(deg)), math.cos(math.radians(deg)), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    T = lambda x, y, z: _trs([1, 1, 1], [x, y, z])
+    S = lambda x, y, z: _trs([x, y, z], [0, 0, 0])
+    _add(s, rect, T(0, 0, 0) @ rx(-90) @ S(3, 3, 1), floor, uv=uv_rect)          # floor  (normal +y)
+    _add(s, rect, T(0, 3, 0) @ rx(90) @ S(3, 3, 1), white)                        # ceiling
+    _add(s, rect, T(0, 1.5, -3) @ S(3, 1.5, 1), white)                            # back wall (normal +z)
+    _add(s, rect, T(-3, 1.5, 0) @ (rz(0) @ np.array([[0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 0, 1]], np.float32)) @ S(3, 1.5, 1), white)
+    _add(s, rect, T(3, 1.5, 0) @ np.array([[0, 0, -1, 0], [0, 1, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float32) @ S(3, 1.5, 1), white)
+    _add(s, rect, T(0, 2.98, 0) @ rx(90) @ S(0.6, 0.6, 1), white, emission=[12.0, 11.0, 9.0])
+    sp = uv_sphere()
+    def add_sphere(center, r, mat):
+        pos, nrm, idx, uv = sp
+        s.add_mesh((pos * np.float32(r) + np.array(center, np.float32)).astype(np.float32), idx, mat, normal=nrm, uv=uv)
+    add_sphere([-1.9, 0.5, -1.2], 0.5, mirror)
+    add_sphere([-0.7, 0.5, -1.4], 0.5, glass)
+    add_sphere([0.5, 0.5, -1.2], 0.5, metal)
+    add_sphere([1.8, 0.5, -1.5], 0.5, disney)
+    _add(s, cube, _trs([0.35, 0.35, 0.35], [-1.5, 0.35, 0.6], 25), metal_aniso)
+    _add(s, cube, _trs([0.35, 0.35, 0.35], [-0.3, 0.35, 0.8], -15), disney_metal)
+    _add(s, cube, _trs([0.35, 0.35, 0.35], [0.9, 0.35, 0.6], 40), substrate)
+    _add(s, rect, T(1.9, 0.8, 0.4) @ S(0.5, 0.8, 1), null_glass)                   # Q7/Q17: surface without BSDF
+    if with_delta_lights:
+        s.add_point_light([2.0, 2.2, 1.5], [6.0, 6.0, 5.0])
+        s.add_directional_light([0.3, 1.0, 0.5], [0.4, 0.4, 0.5])
+    cam = look_at_camera([0.0, 1.6, 5.5], [0.0, 1.0, 0.0], [0, 1, 0], 38.0, resolution)
+    return cam, s
+
+
+def triangle_soup(n_tris=20000, seed=1, resolution=(64, 64), extent=4.0, size=0.25):
+    """Seeded random triangles (matte, one emissive quad): a BVH stress scene for traversal parity
+    and for roofline measurements on a tree that does not fit in L1/LDS."""
+    rng = np.random.default_rng(seed)
+    s = RenderScene()
+    mats = [s.add_material(abi.MAT_MATTE, [s.const_rgb(rng.uniform(0.2, 0.9, 3))]) for _ in range(8)]
+    c = rng.uniform(-extent, extent, (n_tris, 1, 3)).astype(np.float32)
+    pos = (c + rng.normal(0, size, (n_tris, 3, 3)).astype(np.float32)).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(n_tris * 3, dtype=np.uint32).reshape(-1, 3)
+    per = n_tris // len(mats)
+    for k, m in enumerate(mats):
+        a, b = k * per, (n_tris if k == len(mats) - 1 else (k + 1) * per)
+        sub = idx[a:b] - 3 * a
+        s.add_mesh(pos[3 * a:3 * b], sub, m)
+    rect = gen_rectangle()
+    m = _trs([1.5, 1.5, 1.0], [0, 0, 0])
+    up = np.array([[1, 0, 0, 0], [0, 0, 1, extent + 1.0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)
+    _add(s, rect, up @ m, mats[0], emission=[20.0, 20.0, 20.0])
+    cam = look_at_camera([0.0, 0.5, 3.0 * extent], [0, 0, 0], [0, 1, 0], 40.0, resolution)
+    return cam, s
