@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render() hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): Cornell Box 1024x1024, 256 spp, max depth 15, Sobol sampler,
+Lambertian + area light.  One *step* = one complete PathIntegrator::render of that frame with the
+film accumulators resident in HBM.  With N GPUs the film's rows are split into N bands (strong
+scaling, each rank traces its band plus the 2-row filter halo); the bands are gathered on rank 0
+with one RCCL collective inside the timed region.  `value` = all rays of the frame / step time.
+
+The JSON line carries:
+  roofline     -- dominant kernel = BVH traversal (k_trace): algorithmic bytes per ray
+                  (32 ray in + 32 per node visited + 48 per triangle tested + 16 hit out, the
+                  per-ray node/triangle counts measured by device counters in an untimed render of
+                  the same frame) x rays / summed k_trace time from HIP events recorded on the
+                  render stream inside the timed steps;  peak = 8 TB/s HBM3E.
+  cpu_baseline -- the oracle (C++ restatement of the reference's CPU path, kind "port") timed on
+                  this box's host cores on a bounded band of the same frame.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, DEPTH = 1024, 1024, 256, 15
+SCENE = os.path.join(ROOT, "tests", "golden", "cornell-box.xml")
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(pkg, rows=24):
+    """Oracle (CPU port of the reference path) on rows [500, 500+rows) of the same frame."""
+    from oracle import orc
+
+    cam, scene = pkg.import_scene(SCENE, (WIDTH, HEIGHT))
+    o = orc.OracleScene(scene)
+    cores = os.cpu_count() or 1
+    p = orc.make_params(WIDTH, HEIGHT, SPP, DEPTH, row_begin=500, row_end=500 + rows)
+    t = time.time()
+    _, _, st = o.render(cam, p, n_threads=cores)
+    dt = time.time() - t
+    rays = st.rays_extension + st.rays_shadow + st.rays_mis
+    return {
+        "value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "msample_per_s": st.samples / dt / 1e6,
+        "sample": "output rows 500..%d of the 1024x1024/256spp/depth-15 Cornell frame (%d li() samples, %d rays, %.1f s, %d threads, 16x16 tiles, dynamic queue)"
+                  % (500 + rows, st.samples, rays, dt, cores),
+        "nodes_per_ray": st.nodes_visited / max(rays, 1), "tris_per_ray": st.tris_tested / max(rays, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--res", type=int, default=WIDTH)
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--paths-per-pass", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("pathtracer-rs_amd")
+    par = importlib.import_module("pathtracer-rs_amd.parallel")
+    W = H = args.res
+    cam, scene = pkg.import_scene(SCENE, (W, H))
+    integ = pkg.PathIntegrator(pkg.SamplerBuilder(args.spp, cam.film.get_sample_bounds()), args.depth, device=local_rank, paths_per_pass=args.paths_per_pass)
+    integ.preprocess(scene)
+    row_b, row_e = par.band_for_rank(H, rank, world)
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(flags):
+        film.zero_()
+        st = integ.render_device(cam, scene, film.data_ptr(), stream=stream, row_begin=row_b, row_end=row_e, flags=flags)
+        if world > 1:
+            par.gather_film_rows(film, H, rank, world)
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: counters for the roofline's per-ray node / triangle averages, then warm-up
+    cst = step(pkg.abi.FLAG_COUNTERS)
+    c_rays = cst.rays
+    nodes_per_ray, tris_per_ray = cst.nodes_visited / max(c_rays, 1), cst.tris_tested / max(c_rays, 1)
+    for _ in range(args.warmup):
+        step(pkg.abi.FLAG_TIMING)
+    sync()
+    t0 = time.perf_counter()
+    rays = samples = 0
+    ms_trace = ms_shade = ms_film = 0.0
+    trace_launches = 0
+    for _ in range(args.steps):
+        st = step(pkg.abi.FLAG_TIMING)
+        rays += st.rays
+        samples += st.samples
+        ms_trace += st.ms_trace
+        ms_shade += st.ms_shade
+        ms_film += st.ms_film
+        trace_launches += st.trace_launches
+    sync()
+    dt = time.perf_counter() - t0
+
+    vals = torch.tensor([dt, float(rays), float(samples), ms_trace, ms_shade, ms_film, float(trace_launches), nodes_per_ray * c_rays, tris_per_ray * c_rays, float(c_rays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = vals.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = vals.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+        rays, samples = float(sm[1]), float(sm[2])
+        ms_trace = float(mx[3])
+        nodes_per_ray, tris_per_ray = float(sm[7]) / float(sm[9]), float(sm[8]) / float(sm[9])
+        rays_rank0 = float(vals[1])
+    else:
+        rays_rank0 = float(rays)
+    if rank == 0:
+        b_ray = 32.0 + 32.0 * nodes_per_ray + 48.0 * tris_per_ray + 16.0
+        # rank 0's own kernel: its rays x algorithmic bytes / its summed k_trace time
+        achieved = (rays_rank0 * b_ray) / (float(vals[3]) * 1e-3) / 1e9 if float(vals[3]) > 0 else 0.0
+        out = {
+            "metric": "Mray/s, Cornell Box %dx%d, %d spp, depth %d (Msample/s in config)" % (W, H, args.spp, args.depth),
+            "value": rays / dt / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (data/cornell-box.xml as parsed, deterministic Sobol sequence)",
+            "config": {"workload": "cornell-box %dx%d spp=%d max_depth=%d, Lambertian + area light (BASELINE configs[1])" % (W, H, args.spp, args.depth),
+                       "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world,
+                       "ms_trace_per_step": ms_trace / args.steps, "ms_shade_per_step": float(vals[4]) / args.steps, "ms_film_per_step": float(vals[5]) / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_trace (BVH closest-hit / any-hit traversal)", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+                         "avg_launch_ms": float(vals[3]) / max(float(vals[6]), 1.0), "launches": int(float(vals[6]))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
