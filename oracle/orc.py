@@ -136,7 +136,8 @@ def bsdf_eval(material, tex_values, wo, u):
     m.flags = material.get("flags", 0)
     m.inner = -1
     tv = np.zeros((6, 3), dtype=np.float32)
-    tv[: len(tex_values)] = np.asarray(tex_values, dtype=np.float32)
+    if len(tex_values):
+        tv[: len(tex_values)] = np.asarray(tex_values, dtype=np.float32)
     wo = np.ascontiguousarray(wo, dtype=np.float32).reshape(-1, 3)
     u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2)
     out = np.zeros((wo.shape[0], 8), dtype=np.float32)

@@ -109,7 +109,7 @@ def triangle_soup(n_tris=20000, seed=1, resolution=(64, 64), extent=4.0, size=0.
         s.add_mesh(pos[3 * a:3 * b], sub, m)
     rect = gen_rectangle()
     m = _trs([1.5, 1.5, 1.0], [0, 0, 0])
-    up = np.array([[1, 0, 0, 0], [0, 0, 1, extent + 1.0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)
+    up = np.array([[1, 0, 0, 0], [0, 0, -1, extent + 1.0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32)  # quad facing down
     _add(s, rect, up @ m, mats[0], emission=[20.0, 20.0, 20.0])
     cam = look_at_camera([0.0, 0.5, 3.0 * extent], [0, 0, 0], [0, 1, 0], 40.0, resolution)
     return cam, s

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ from the CPU oracle (oracle/liboracle.so).
+
+The reference cannot be executed in this environment (Rust, no toolchain) and its own tests hold no
+vectors for this path, so these fixtures pin the ORACLE against regressions ("parity unpinned"
+w.r.t. the reference).  Contents (SURVEY.md section 8c list):
+  sobol_grid.npz     (pixel, sample, dim) -> f32 and interval indices for three sampler configs
+  cornell_hits.npz   ray -> (prim, t, b0, b1, b2) on the Cornell box
+  lobes.npz          per-material sample_f / pdf grids
+  cornell_film_d4.npz, cornell_film_d15.npz   64x64, 16 spp film (rgb, weight) + ray counts
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import orc  # noqa: E402
+
+pkg_scene = importlib.import_module("pathtracer-rs_amd.scene")
+abi = importlib.import_module("pathtracer-rs_amd.abi")
+
+LOBE_CASES = {
+    "matte": (dict(kind=abi.MAT_MATTE, tex=[0]), [[0.5, 0.6, 0.7]]),
+    "mirror": (dict(kind=abi.MAT_MIRROR, tex=[]), []),
+    "glass": (dict(kind=abi.MAT_GLASS, tex=[0, 1, 2]), [[1, 1, 1], [0.9, 0.8, 1.0], [1.5, 0, 0]]),
+    "metal": (dict(kind=abi.MAT_METAL, tex=[0, 1, 2, 3, -1, -1]), [[0.2, 0.92, 1.1], [3.9, 2.45, 2.14], [1, 1, 1], [0.15, 0, 0]]),
+    "metal_remap": (dict(kind=abi.MAT_METAL, tex=[0, 1, 2, -1, 4, 5], flags=1), [[0.14, 0.37, 1.44], [3.98, 2.38, 1.6], [0.9, 0.9, 0.9], [0, 0, 0], [0.3, 0, 0], [0.05, 0, 0]]),
+    "disney": (dict(kind=abi.MAT_DISNEY, tex=[0, 1, 2, 3]), [[0.8, 0.5, 0.2], [0.3, 0, 0], [1.5, 0, 0], [0.4, 0, 0]]),
+    "disney_metal": (dict(kind=abi.MAT_DISNEY, tex=[0, 1, 2, 3]), [[0.8, 0.5, 0.2], [1.0, 0, 0], [1.5, 0, 0], [0.25, 0, 0]]),
+    "substrate": (dict(kind=abi.MAT_SUBSTRATE, tex=[0, 1, 2, 3]), [[0.1, 0.5, 0.2], [0.04, 0.04, 0.04], [0.1, 0, 0], [0.2, 0, 0]]),
+}
+
+
+def lobe_inputs():
+    rng = np.random.default_rng(11)
+    n = 256
+    wo = rng.normal(size=(n, 3))
+    wo[:, 2] = np.abs(wo[:, 2]) + 0.05
+    wo[n // 2:, 2] *= -1.0
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    return wo.astype(np.float32), rng.uniform(0, 1, (n, 2)).astype(np.float32)
+
+
+def cornell_rays(cam, n=4096, seed=3):
+    rng = np.random.default_rng(seed)
+    o = np.tile(cam.trans, (n, 1)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 2, 2] = -8.0 * np.abs(d[: n // 2, 2]) - 4.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o[n // 2:] = rng.uniform([-0.9, 0.1, -0.9], [0.9, 1.9, 0.9], size=(n - n // 2, 3)).astype(np.float32)
+    return np.concatenate([o, d.astype(np.float32), np.full((n, 1), np.inf, np.float32)], axis=1)
+
+
+def main():
+    rng = np.random.default_rng(5)
+    out = {}
+    for tag, (w, h, spp) in {"cfg1": (256, 256, 16), "cfg2": (1024, 1024, 256), "cfg5": (3840, 2160, 512)}.items():
+        n = 512
+        px, py = rng.integers(-2, w + 2, n), rng.integers(-2, h + 2, n)
+        sn, dm = rng.integers(0, spp, n), rng.integers(0, 64, n)
+        v, idx = orc.sobol_samples(orc.make_params(w, h, spp, 4), px, py, sn, dm)
+        out.update({tag + "_px": px, tag + "_py": py, tag + "_sn": sn, tag + "_dim": dm, tag + "_val": v, tag + "_idx": idx})
+    np.savez_compressed(os.path.join(HERE, "sobol_grid.npz"), **out)
+
+    cam, scene = pkg_scene.import_scene(os.path.join(HERE, "cornell-box.xml"), (64, 64))
+    o = orc.OracleScene(scene)
+    rays = cornell_rays(cam)
+    hits, _ = o.trace_rays(rays)
+    np.savez_compressed(os.path.join(HERE, "cornell_hits.npz"), rays=rays, prim=hits["prim"], t=hits["t"], b0=hits["b0"], b1=hits["b1"], b2=hits["b2"])
+
+    wo, u = lobe_inputs()
+    lob = {"wo": wo, "u": u}
+    for name, (mat, tv) in LOBE_CASES.items():
+        lob[name] = orc.bsdf_eval(mat, tv, wo, u)
+    np.savez_compressed(os.path.join(HERE, "lobes.npz"), **lob)
+
+    for depth in (4, 15):
+        film, _, st = o.render(cam, orc.make_params(64, 64, 16, depth), n_threads=1)
+        np.savez_compressed(os.path.join(HERE, "cornell_film_d%d.npz" % depth), rgb=film["rgb"], weight=film["weight"],
+                            rays=np.array([st.rays_extension, st.rays_shadow, st.rays_mis, st.samples], dtype=np.uint64))
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

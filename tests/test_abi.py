@@ -1,0 +1,55 @@
+"""The C-ABI shared library: loads, exports every symbol include/ptrs.h declares, agrees with the
+ctypes mirror on struct sizes, and fails loudly (never silently falls back) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import CORNELL, ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ptrs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptrs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(ptrs):
+    L = ptrs.load_library()
+    names = _declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.ptrs_abi_version() == 1
+
+
+def test_struct_sizes_match_binding(ptrs):
+    L = ptrs.load_library()
+    a = ptrs.abi
+    for i, s in enumerate([a.PtrsTexture, a.PtrsMaterial, a.PtrsMesh, a.PtrsLight, a.PtrsBvhNode, a.PtrsSceneDesc, a.PtrsCamera, a.PtrsRenderParams, a.PtrsStats, a.PtrsHit]):
+        assert L.ptrs_abi_sizeof(i) == C.sizeof(s), s.__name__
+    assert L.ptrs_abi_sizeof(10) == 16 and a.FILM_DTYPE.itemsize == 16 and a.HIT_DTYPE.itemsize == 20
+
+
+def test_no_cpu_fallback(ptrs):
+    """Without a GPU the product path must raise (this container has none).  On a GPU box the same
+    call succeeds, which the -m gpu tests cover."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cam, scene = ptrs.import_scene(CORNELL, (8, 8))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(1, cam.film.get_sample_bounds()), 2)
+    with pytest.raises(Exception) as e:
+        integ.render(cam, scene)
+    assert "no HIP device" in str(e.value)
+
+
+def test_sampler_builder_mirror(ptrs):
+    """SobolSamplerBuilder::new (sobol.rs:35-60): spp rounded up to a power of two (Q4),
+    resolution = round_up_pow2(max extent), log2."""
+    with pytest.warns(UserWarning):
+        sb = ptrs.SamplerBuilder(100, (-2, -2, 1026, 1026))
+    assert (sb.samples_per_pixel, sb.resolution, sb.log_2_resolution) == (128, 2048, 11)
+    sb = ptrs.SamplerBuilder(16, (-2, -2, 258, 258))
+    assert (sb.samples_per_pixel, sb.resolution, sb.log_2_resolution) == (16, 512, 9)
