@@ -43,45 +43,56 @@ PT_HD void load_tri(const DTri *tris, uint32_t k, f3 &p0, f3 &p1, f3 &p2, uint32
 }
 
 // ANY = false: closest hit (intersect); ANY = true: any hit (intersect_p).
-// Stack must provide push(uint32_t), pop() and empty().
+// Stack must provide push(uint32_t), pop(), empty() and clear().
+//
+// "while-while" form: each lane first walks interior nodes until it reaches a leaf that passes the
+// slab test (or runs out of nodes), and only then are the leaf's triangles tested -- so that on a
+// 64-lane wave the (expensive) triangle phase runs with most lanes active instead of once per
+// interior step.  Per ray the sequence of nodes and triangles visited is exactly that of the
+// reference loop (accelerator.rs:372-414), only the interleaving between lanes differs.
 template <bool ANY, class Stack>
 PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
     out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f;
+    stack.clear(); // an any-hit query may have returned early and left entries behind
     if (sc.n_nodes == 0) return false;
     f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
-    uint32_t cur = 0;
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t cur = 0; // node to visit next, NONE when the traversal is over
     bool hit = false;
-    for (;;) {
-        const v4 *np = reinterpret_cast<const v4 *>(sc.nodes + cur);
-        v4 a = np[0], b = np[1];
-        ++n_nodes;
-        bool descend = false;
-        if (slab_test(a, b, o, inv, neg, t_max)) {
-            uint32_t offset = f2u(b.z), meta = f2u(b.w);
-            uint32_t nprims = meta & 0xffffu;
-            if (nprims > 0) {
-                for (uint32_t i = 0; i < nprims; ++i) {
-                    f3 p0, p1, p2; uint32_t prim, flags;
-                    load_tri(sc.tris, offset + i, p0, p1, p2, prim, flags);
-                    ++n_tris;
-                    TriHit h;
-                    if (tri_test(o, d, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
-                        if (ANY) { out.prim = 0; return true; }
-                        hit = true; t_max = h.t;
-                        out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2;
-                    }
+    while (cur != NONE) {
+        // phase 1: descend until a leaf is accepted
+        uint32_t leaf_first = 0, leaf_count = 0;
+        while (cur != NONE) {
+            const v4 *np = reinterpret_cast<const v4 *>(sc.nodes + cur);
+            const v4 a = np[0], b = np[1];
+            ++n_nodes;
+            if (slab_test(a, b, o, inv, neg, t_max)) {
+                const uint32_t offset = f2u(b.z), meta = f2u(b.w);
+                const uint32_t nprims = meta & 0xffffu;
+                if (nprims > 0) {
+                    leaf_first = offset; leaf_count = nprims;
+                    cur = stack.empty() ? NONE : stack.pop();
+                    break;
                 }
-            } else {
-                uint32_t axis = (meta >> 16) & 0xffu;
+                const uint32_t axis = (meta >> 16) & 0xffu;
                 if (neg[axis]) { stack.push(cur + 1); cur = offset; }
                 else { stack.push(offset); cur = cur + 1; }
-                descend = true;
+            } else {
+                cur = stack.empty() ? NONE : stack.pop();
             }
         }
-        if (!descend) {
-            if (stack.empty()) break;
-            cur = stack.pop();
+        // phase 2: the leaf's triangles, in order
+        for (uint32_t i = 0; i < leaf_count; ++i) {
+            f3 p0, p1, p2; uint32_t prim, flags;
+            load_tri(sc.tris, leaf_first + i, p0, p1, p2, prim, flags);
+            ++n_tris;
+            TriHit h;
+            if (tri_test(o, d, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
+                if (ANY) { out.prim = 0; return true; }
+                hit = true; t_max = h.t;
+                out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2;
+            }
         }
     }
     return hit;
@@ -92,6 +103,7 @@ struct LocalStack { // host twin / small fixed uses
     PT_MEM void push(uint32_t v) { s[n++] = v; }
     PT_MEM uint32_t pop() { return s[--n]; }
     PT_MEM bool empty() const { return n == 0; }
+    PT_MEM void clear() { n = 0; }
 };
 
 } // namespace pt

@@ -12,7 +12,7 @@
 namespace pt {
 
 enum : uint32_t { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum : int { LOBE_LAMBERT = 0, LOBE_SPEC_REFL = 1, LOBE_FRESNEL_SPEC = 2, LOBE_MICRO_REFL = 3, LOBE_FRESNEL_BLEND = 4, LOBE_DISNEY_DIFFUSE = 5 };
+enum : int { LOBE_LAMBERT = 0, LOBE_SPEC_REFL = 1, LOBE_FRESNEL_SPEC = 2, LOBE_MICRO_REFL = 3, LOBE_FRESNEL_BLEND = 4, LOBE_DISNEY_DIFFUSE = 5, LOBE_ABSENT = 6 };
 enum : int { FR_NOOP = 0, FR_CONDUCTOR = 1, FR_DISNEY = 2 };
 
 PT_HD float cos2_theta(f3 w) { return w.z * w.z; }
@@ -91,6 +91,7 @@ PT_HD uint32_t lobe_type(const Lobe &l) {
         case LOBE_LAMBERT: case LOBE_DISNEY_DIFFUSE: return BSDF_REFLECTION | BSDF_DIFFUSE;
         case LOBE_SPEC_REFL: return BSDF_REFLECTION | BSDF_SPECULAR;
         case LOBE_FRESNEL_SPEC: return BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+        case LOBE_ABSENT: return 0x100u; // matches no query: an empty slot
         default: return BSDF_REFLECTION | BSDF_GLOSSY;
     }
 }
@@ -262,66 +263,83 @@ PT_HD f3 lobe_sample_f(const Lobe &l, f3 wo, f3 &wi, f2 u, float &pdf, uint32_t 
 }
 
 // ---- BSDF container (bsdf.rs) ---------------------------------------------------------------------
-struct Bsdf {
+// NL = number of lobe slots of the material (compile time); slot i is live when i < n.  All loops
+// are fully unrolled over constant indices so the lobes stay in registers and, with the lobe
+// kinds assigned as constants by make_bsdf<MAT>, every switch on `kind` folds away.
+template <int NL> struct BsdfT {
     float eta;
     f3 ns, ng, ss, ts;
     int n;
-    Lobe lobe[2];
+    Lobe lobe[NL];
 };
-PT_HD void bsdf_init(Bsdf &b, const Surface &s, float eta) { // bsdf.rs:20-34
+template <int NL> PT_HD void bsdf_init(BsdfT<NL> &b, const Surface &s, float eta) { // bsdf.rs:20-34
     b.eta = eta; b.ns = s.ns; b.ng = s.n; b.ss = normalize(s.s_dpdu); b.ts = cross(b.ns, b.ss); b.n = 0;
 }
-PT_HD f3 to_local(const Bsdf &b, f3 v) { return mk3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
-PT_HD f3 to_world(const Bsdf &b, f3 v) {
+template <int NL> PT_HD f3 to_local(const BsdfT<NL> &b, f3 v) { return mk3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
+template <int NL> PT_HD f3 to_world(const BsdfT<NL> &b, f3 v) {
     return mk3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z, b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
 }
-PT_HD int bsdf_num(const Bsdf &b, uint32_t flags) { int c = 0; for (int i = 0; i < b.n; ++i) c += lobe_matches(b.lobe[i], flags) ? 1 : 0; return c; }
+template <int NL> PT_HD int bsdf_num(const BsdfT<NL> &b, uint32_t flags) {
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) c += (i < b.n && lobe_matches(b.lobe[i], flags)) ? 1 : 0;
+    return c;
+}
 PT_HD bool lobe_side_ok(const Lobe &l, bool refl) { uint32_t t = lobe_type(l); return (refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION)); }
 
-PT_HD f3 bsdf_f(const Bsdf &b, f3 wo_w, f3 wi_w, uint32_t flags) { // bsdf.rs:150-187
+template <int NL> PT_HD f3 bsdf_f(const BsdfT<NL> &b, f3 wo_w, f3 wi_w, uint32_t flags) { // bsdf.rs:150-187
     f3 wi = to_local(b, wi_w), wo = to_local(b, wo_w);
     if (wo.z == 0.0f) return splat3(0.0f);
     bool refl = dot(wi_w, b.ng) * dot(wo_w, b.ng) > 0.0f;
     f3 f = splat3(0.0f);
-    for (int i = 0; i < b.n; ++i)
-        if (lobe_matches(b.lobe[i], flags) && lobe_side_ok(b.lobe[i], refl)) f = f + lobe_f(b.lobe[i], wo, wi);
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+        if (i < b.n && lobe_matches(b.lobe[i], flags) && lobe_side_ok(b.lobe[i], refl)) f = f + lobe_f(b.lobe[i], wo, wi);
     return f;
 }
-PT_HD float bsdf_pdf(const Bsdf &b, f3 wo_w, f3 wi_w, uint32_t flags) { // bsdf.rs:189-222
+template <int NL> PT_HD float bsdf_pdf(const BsdfT<NL> &b, f3 wo_w, f3 wi_w, uint32_t flags) { // bsdf.rs:189-222
     if (b.n == 0) return 0.0f;
     f3 wo = to_local(b, wo_w), wi = to_local(b, wi_w);
     if (wo.z == 0.0f) return 0.0f;
     float pdf = 0.0f; int m = 0;
-    for (int i = 0; i < b.n; ++i)
-        if (lobe_matches(b.lobe[i], flags)) { ++m; pdf += lobe_pdf(b.lobe[i], wo, wi); }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+        if (i < b.n && lobe_matches(b.lobe[i], flags)) { ++m; pdf += lobe_pdf(b.lobe[i], wo, wi); }
     return m > 0 ? pdf / (float)m : 0.0f;
 }
 // bsdf.rs:66-148.  wi_w is only written when a direction was sampled (like the reference).
-PT_HD f3 bsdf_sample_f(const Bsdf &b, f3 wo_w, f3 &wi_w, f2 u, float &pdf, uint32_t flags, uint32_t &sampled) {
+template <int NL> PT_HD f3 bsdf_sample_f(const BsdfT<NL> &b, f3 wo_w, f3 &wi_w, f2 u, float &pdf, uint32_t flags, uint32_t &sampled) {
     int m = bsdf_num(b, flags);
     if (m == 0) { pdf = 0.0f; sampled = 0; return splat3(0.0f); }
     int comp_i = (int)floor_(u.x * (float)m);
     if (comp_i > m - 1) comp_i = m - 1;
     int sel = -1, count = comp_i;
-    for (int i = 0; i < b.n; ++i)
-        if (lobe_matches(b.lobe[i], flags)) { if (count == 0) { sel = i; break; } --count; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+        if (sel < 0 && i < b.n && lobe_matches(b.lobe[i], flags)) { if (count == 0) sel = i; else --count; }
     f2 ur = mk2((u.x * (float)m) - (float)comp_i, u.y);
     f3 wi = splat3(0.0f), wo = to_local(b, wo_w);
     pdf = 0.0f;
-    sampled = lobe_type(b.lobe[sel]);
-    f3 f = lobe_sample_f(b.lobe[sel], wo, wi, ur, pdf, sampled);
+    f3 f = splat3(0.0f);
+    uint32_t sel_type = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+        if (i == sel) { sel_type = lobe_type(b.lobe[i]); sampled = sel_type; f = lobe_sample_f(b.lobe[i], wo, wi, ur, pdf, sampled); }
     if (pdf == 0.0f) { sampled = 0; return splat3(0.0f); }
     wi_w = to_world(b, wi);
-    bool spec = (lobe_type(b.lobe[sel]) & BSDF_SPECULAR) != 0;
-    if (!spec && m > 1)
-        for (int i = 0; i < b.n; ++i)
-            if (i != sel && lobe_matches(b.lobe[i], flags)) pdf += lobe_pdf(b.lobe[i], wo, wi);
+    bool spec = (sel_type & BSDF_SPECULAR) != 0;
+    if (!spec && m > 1) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i < b.n && i != sel && lobe_matches(b.lobe[i], flags)) pdf += lobe_pdf(b.lobe[i], wo, wi);
+    }
     if (m > 1) pdf /= (float)m;
     if (!spec && m > 1) {
         bool refl = dot(wi_w, b.ng) * dot(wo_w, b.ng) > 0.0f;
         f = splat3(0.0f);
-        for (int i = 0; i < b.n; ++i)
-            if (lobe_matches(b.lobe[i], flags) && lobe_side_ok(b.lobe[i], refl)) f = f + lobe_f(b.lobe[i], wo, wi);
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (i < b.n && lobe_matches(b.lobe[i], flags) && lobe_side_ok(b.lobe[i], refl)) f = f + lobe_f(b.lobe[i], wo, wi);
     }
     return f;
 }

@@ -2,14 +2,15 @@
 //
 // The pipeline restates PathIntegrator::li (src/pathtracer/integrator.rs:392-503) as a loop over
 // stages; one loop iteration of the reference = one pass through
-//     extend (trace) -> sort -> shade -> connect (trace shadow, trace MIS) -> resolve
+//     extend (trace + epilogue/bucketing) -> shade[material] -> connect (shadow + MIS queries, resolve)
 // with path state in HBM between stages.  The functions below do the arithmetic; the HIP kernels
 // in kernels.hip (and, for CPU debugging only, tests/host_twin) wrap them with the queue logic.
 //   generate_item : integrator.rs:571-577 + sobol.rs:81-120 + pathtracer/mod.rs:59-81 + ray.rs:30-35
-//   sort_item     : integrator.rs:418-431 (emission, miss, depth cut) + material bucket
-//   shade_item    : integrator.rs:433-499, uniform_sample_one_light 192-217, estimate_direct 23-135
-//                   up to (not including) the two scene queries
-//   resolve_item  : estimate_direct's use of the query results (66-78, 121-134) and `l += ld` (444-446)
+//   extension_epilogue : integrator.rs:418-431 (emission, miss, depth cut) + material bucket
+//   shade_item<MAT>    : integrator.rs:433-499, uniform_sample_one_light 192-217, estimate_direct
+//                        23-135 up to (not including) its two scene queries
+//   connect_item       : those two queries (shadow any-hit, MIS closest-hit) and estimate_direct's
+//                        use of their results (66-78, 121-134), `l += ld` (444-446)
 //   film_item     : FilmTile::add_sample (film.rs:60-106) turned into a per-pixel gather
 #pragma once
 #include "pt_bvh.h"
@@ -77,28 +78,30 @@ PT_HD int material_bucket(const DScene &sc, int32_t mat) {
     return m.kind;
 }
 
-// returns the material bucket (0..6) when the path goes on to shading, -1 when it ends here
-PT_HD int sort_item(const DParams &R, const DScene &sc, const DPaths &P, uint32_t pid) {
-    u4 st = P.st[pid];
-    u4 h = P.hit[pid];
-    const int32_t prim = (int32_t)h.x;
-    const int32_t bounces = st_bounces(st.z);
-    if (bounces == 0 || (st.z & ST_SPECULAR)) {
+// Epilogue of the extension trace (integrator.rs:418-431): emission at the first vertex / after a
+// specular bounce, environment radiance for escaped rays, the depth cut -- then the material bucket.
+// Returns the bucket (0..5) when the path goes on to shading, -1 when it ends here.
+template <int FEAT>
+PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P, uint32_t pid, const HitRec &h) {
+    const uint32_t stz = P.st[pid].z;
+    const int32_t prim = h.prim;
+    const int32_t bounces = st_bounces(stz);
+    if (bounces == 0 || (stz & ST_SPECULAR)) {
         if (prim >= 0) {
             const DTriShade &T = sc.shade[prim];
             if (T.light >= 0) {
                 f3 d = xyz(P.ray_d[pid]);
-                Surface s = tri_surface(T, prim, u2f(h.y), u2f(h.z), u2f(h.w), -d);
-                f3 le = surface_le(sc, T, s, -d);
+                Surface s = tri_surface(T, prim, h.b0, h.b1, h.b2, -d);
+                f3 le = surface_le<FEAT>(sc, T, s, -d);
                 v4 Lv = P.L[pid];
                 f3 L = xyz(Lv) + xyz(P.beta[pid]) * le;
                 P.L[pid] = mkv4(L, Lv.w);
             }
-        } else if (sc.n_inf > 0) {
+        } else if ((FEAT & FEAT_INFINITE) && sc.n_inf > 0) {
             f3 d = xyz(P.ray_d[pid]);
             v4 Lv = P.L[pid];
             f3 L = xyz(Lv), beta = xyz(P.beta[pid]);
-            for (uint32_t i = 0; i < sc.n_inf; ++i) L = L + beta * light_le(sc, sc.lights[sc.inf_lights[i]], d);
+            for (uint32_t i = 0; i < sc.n_inf; ++i) L = L + beta * light_le<FEAT>(sc, sc.lights[sc.inf_lights[i]], d);
             P.L[pid] = mkv4(L, Lv.w);
         }
     }
@@ -108,6 +111,7 @@ PT_HD int sort_item(const DParams &R, const DScene &sc, const DPaths &P, uint32_
 
 struct ShadeResult { bool next; bool nee; bool shadow; bool mis; };
 
+template <int MAT, int FEAT>
 PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid) {
     ShadeResult out; out.next = false; out.nee = false; out.shadow = false; out.mis = false;
     const f3 ro = xyz(P.ray_o[pid]);
@@ -127,13 +131,15 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 
     const f3 wo = -rd;
     Surface s = tri_surface(T, prim, u2f(h.y), u2f(h.z), u2f(h.w), wo);
-    if (stv.z & ST_HAS_DIFF) { // only the camera ray carries differentials (Q9)
+    // Only the camera ray carries differentials (Q9) and only image-texture lookups read them
+    // (texture.rs:185-191, 430-445), so without image textures they are dead values.
+    if ((FEAT & FEAT_IMAGE) && (stv.z & ST_HAS_DIFF)) {
         v4 pf = P.pfilm[pid];
         CamRay cr = camera_ray(C, mk2(pf.x, pf.y), R.inv_sqrt_spp);
         surface_differentials(s, ro, cr.rx_d, ro, cr.ry_d);
     }
-    Bsdf bsdf;
-    if (!make_bsdf(sc, T.material, s, bsdf)) { // integrator.rs:434-439 (Q7)
+    BsdfT<MatLobes<MAT>::N> bsdf;
+    if (!make_bsdf<MAT, FEAT>(sc, T.material, s, bsdf)) { // integrator.rs:434-439 (Q7)
         f3 o2 = spawn_origin(s.p, s.p_error, s.n, rd);
         P.ray_o[pid] = mkv4(o2, PT_INF);
         stv.z = st_pack(ss.dim, stv.z & ST_SPECULAR, bounces - 1);
@@ -153,7 +159,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         const DLight &Lt = sc.lights[li];
         const bool delta = light_is_delta(Lt);
         LightSample ls;
-        light_sample_li(sc, Lt, s.p, s.p_error, s.n, u_light, ls);
+        light_sample_li<FEAT>(sc, Lt, s.p, s.p_error, s.n, u_light, ls);
         f3 A = splat3(0.0f);
         float spdf = 0.0f;
         f3 wi = ls.wi;
@@ -178,7 +184,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             if (!is_black(fB) && spdf > 0.0f) {
                 bool ok = true;
                 if (!(sampled & BSDF_SPECULAR)) {
-                    float lpdf = light_pdf_li(sc, Lt, s.p, s.p_error, s.n, wi);
+                    float lpdf = light_pdf_li<FEAT>(sc, Lt, s.p, s.p_error, s.n, wi);
                     if (lpdf == 0.0f) ok = false; // `return ld` (Q11)
                     else wB = power_heuristic(spdf, lpdf);
                 }
@@ -229,30 +235,52 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     return out;
 }
 
-PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid) {
-    v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
-    u4 n2 = P.nee2[pid];
+// The two scene queries of estimate_direct and its use of their results: shadow any-hit
+// (integrator.rs:66-78, light.rs:38-42), MIS closest hit (119-134), then `l += beta * nLights * ld`
+// (444-446, 206-216).  One NEE record per call.
+template <int FEAT, class Stack>
+PT_HD void connect_item(const DScene &sc, const DPaths &P, uint32_t pid, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
+    const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
+    const u4 n2 = P.nee2[pid];
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
-    const DLight &Lt = sc.lights[li];
     f3 ld = splat3(0.0f);
-    if ((fl & NEE_SHADOW) && P.sh_res[pid] == 0u) ld = ld + xyz(n0);
+    if (fl & NEE_SHADOW) {
+        const v4 o = P.sh_o[pid], d = P.sh_d[pid];
+        HitRec h;
+        if (!bvh_trace<true>(sc, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris)) ld = ld + xyz(n0);
+    }
     if (fl & NEE_MIS) {
-        u4 h = P.mis_hit[pid];
-        f3 wi = xyz(P.mis_d[pid]);
+        const DLight &Lt = sc.lights[li];
+        const v4 o = P.mis_o[pid];
+        const f3 wi = xyz(P.mis_d[pid]);
+        HitRec h;
         f3 l2 = splat3(0.0f);
-        if ((int32_t)h.x >= 0) {
-            const DTriShade &T = sc.shade[(int32_t)h.x];
+        if (bvh_trace<false>(sc, xyz(o), wi, PT_INF, stack, h, n_nodes, n_tris)) {
+            const DTriShade &T = sc.shade[h.prim];
             if (T.light == (int32_t)li) { // std::ptr::eq(light, isect_light) (Q11)
-                Surface s = tri_surface(T, (int32_t)h.x, u2f(h.y), u2f(h.z), u2f(h.w), -wi);
-                l2 = surface_le(sc, T, s, -wi);
+                Surface s = tri_surface(T, h.prim, h.b0, h.b1, h.b2, -wi);
+                l2 = surface_le<FEAT>(sc, T, s, -wi);
             }
-        } else l2 = light_le(sc, Lt, wi);
+        } else l2 = light_le<FEAT>(sc, Lt, wi);
         if (!is_black(l2)) ld = ld + xyz(n1) * l2 * splat3(1.0f) * n0.w / n1.w;
     }
-    f3 beta = mk3(u2f(n2.x), u2f(n2.y), u2f(n2.z));
-    v4 Lv = P.L[pid];
-    f3 L = xyz(Lv) + beta * ((float)sc.n_lights * ld);
+    const f3 beta = mk3(u2f(n2.x), u2f(n2.y), u2f(n2.z));
+    const v4 Lv = P.L[pid];
+    const f3 L = xyz(Lv) + beta * ((float)sc.n_lights * ld);
     P.L[pid] = mkv4(L, Lv.w);
+}
+
+// run-time material dispatch (host twin; the HIP back end launches one specialised kernel per bucket)
+template <int FEAT>
+PT_HD ShadeResult shade_dispatch(int bucket, const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid) {
+    switch (bucket) {
+        case 0: return shade_item<0, FEAT>(R, S, C, sc, P, pid);
+        case 1: return shade_item<1, FEAT>(R, S, C, sc, P, pid);
+        case 2: return shade_item<2, FEAT>(R, S, C, sc, P, pid);
+        case 3: return shade_item<3, FEAT>(R, S, C, sc, P, pid);
+        case 4: return shade_item<4, FEAT>(R, S, C, sc, P, pid);
+        default: return shade_item<5, FEAT>(R, S, C, sc, P, pid);
+    }
 }
 
 // film gather for one output pixel over the current pass.  table = 16x16 Gaussian filter table

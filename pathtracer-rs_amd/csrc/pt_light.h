@@ -31,14 +31,43 @@ PT_HD void tri_sample(const DTriShade &T, f2 u, f3 &p, f3 &n, f3 &perr, f2 &uv) 
     uv = mk2(b0 * T.uv0[0] + b1 * T.uv1[0] + b2 * T.uv2[0], b0 * T.uv0[1] + b1 * T.uv1[1] + b2 * T.uv2[1]);
 }
 
+// the two hit-record fields pdf_at_point needs: p (shape.rs:224) and general.n after
+// set_shading_geometry's face-forwarding (shape.rs:261-356, interaction.rs:200-204) -- same
+// arithmetic as tri_surface, minus everything that does not feed them
+PT_HD void tri_point_normal(const DTriShade &T, float b0, float b1, float b2, f3 &p, f3 &n) {
+    f3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
+    p = b0 * p0 + b1 * p1 + b2 * p2;
+    n = normalize(cross(p0 - p2, p1 - p2));
+    if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) n = -n;
+    if (T.flags & (TRI_HAS_NORMAL | TRI_HAS_TANGENT)) {
+        f3 ns;
+        if (T.flags & TRI_HAS_NORMAL) {
+            ns = b0 * ld3(T.n0) + b1 * ld3(T.n1) + b2 * ld3(T.n2);
+            ns = len2(ns) > 0.0f ? normalize(ns) : n;
+        } else ns = n;
+        f3 ss;
+        if (T.flags & TRI_HAS_TANGENT) {
+            ss = b0 * ld3(T.s0) + b1 * ld3(T.s1) + b2 * ld3(T.s2);
+            if (len2(ss) > 0.0f) ss = normalize(ss);
+            else { f3 du, dv; tri_dpduv(p0, p1, p2, mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), du, dv); ss = normalize(du); }
+        } else { f3 du, dv; tri_dpduv(p0, p1, p2, mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), du, dv); ss = normalize(du); }
+        f3 ts = cross(ss, ns);
+        if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinate_system(ns, ss, ts);
+        if (T.flags & TRI_REVERSE) ts = -ts;
+        n = face_forward(n, normalize(cross(ss, ts)));
+    }
+}
+
 // Triangle::pdf_at_point (shape.rs:62-72): a single-triangle intersection from the offset origin
 PT_HD float tri_pdf_at_point(const DTriShade &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi) {
     f3 o = spawn_origin(ref_p, ref_err, ref_n, wi);
     TriHit h;
     if (!tri_test(o, wi, PT_INF, ld3(T.p0), ld3(T.p1), ld3(T.p2), h)) return 0.0f;
     if (T.flags & TRI_DEGENERATE) return 0.0f;
-    Surface s = tri_surface(T, 0, h.b0, h.b1, h.b2, -wi);
-    return len2(ref_p - s.p) / (fabs_(dot(s.n, -wi)) * area);
+    f3 p, n;
+    tri_point_normal(T, h.b0, h.b1, h.b2, p, n);
+    return len2(ref_p - p) / (fabs_(dot(n, -wi)) * area);
 }
 
 PT_HD f3 env_lookup(const DScene &sc, const DLight &L, f2 st) { return tex_lookup_width(sc, sc.texs[L.lmap_tex], st, 0.0f); }
@@ -56,6 +85,7 @@ PT_HD float dist1d_sample(const float *func, const float *cdf, float func_int, u
 
 // Light::sample_li.  Returns false when the reference leaves the visibility tester unset
 // (InfiniteAreaLight with map_pdf == 0, light.rs:411-413) -- the reference would panic there.
+template <int FEAT>
 PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f2 u, LightSample &o) {
     o.p1_err = splat3(0.0f); o.p1_n = splat3(0.0f);
     if (L.kind == 0) { // point
@@ -78,9 +108,10 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
         o.pdf = tri_pdf_at_point(T, L.area, ref_p, ref_err, ref_n, o.wi);
         o.p1 = p; o.p1_err = perr; o.p1_n = n;
         f3 w = -o.wi;
-        o.li = dot(n, w) > 0.0f ? tex_eval(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f) : splat3(0.0f);
+        o.li = dot(n, w) > 0.0f ? tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f) : splat3(0.0f);
         return true;
     }
+    if (!(FEAT & FEAT_INFINITE)) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; } // unreachable
     // infinite area light
     const float *D = sc.distdata;
     float pdf_v, pdf_u; uint32_t v, dummy;
@@ -97,9 +128,10 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
     return true;
 }
 
+template <int FEAT>
 PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f3 w) {
     if (L.kind == 2) return tri_pdf_at_point(sc.shade[L.tri], L.area, ref_p, ref_err, ref_n, w);
-    if (L.kind == 3) {
+    if ((FEAT & FEAT_INFINITE) && L.kind == 3) {
         f3 wi = xform_vec(L.w2l, w);
         float theta = spherical_theta(wi), phi = spherical_phi(wi);
         float st = pt_sinf(theta);
@@ -119,16 +151,18 @@ PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err
 }
 
 // Light::le for a ray that escapes (light.rs:45-47, 488-498)
+template <int FEAT>
 PT_HD f3 light_le(const DScene &sc, const DLight &L, f3 d) {
-    if (L.kind != 3) return splat3(0.0f);
+    if (!(FEAT & FEAT_INFINITE) || L.kind != 3) return splat3(0.0f);
     f3 w = normalize(xform_vec(L.w2l, d));
     return env_lookup(sc, L, mk2(spherical_phi(w) * PT_INV_2PI, spherical_theta(w) * PT_INV_PI));
 }
 
 // SurfaceMediumInteraction::le (interaction.rs:297-303) + DiffuseAreaLight::l (light.rs:252-258)
+template <int FEAT>
 PT_HD f3 surface_le(const DScene &sc, const DTriShade &T, const Surface &s, f3 w) {
     if (T.light < 0) return splat3(0.0f);
-    if (dot(s.n, w) > 0.0f) return tex_eval(sc, sc.lights[T.light].ke_tex, s);
+    if (dot(s.n, w) > 0.0f) return tex_eval<FEAT>(sc, sc.lights[T.light].ke_tex, s);
     return splat3(0.0f);
 }
 

@@ -18,9 +18,10 @@ PT_HD Lobe blank_lobe(int kind) {
     return l;
 }
 
+template <int FEAT>
 PT_HD void normal_mapping(const DScene &sc, int32_t tex, Surface &s) { // mod.rs:39-79
     f3 c0 = s.s_dpdu, c1 = s.s_dpdv, c2 = s.ns;
-    f3 tn = normalize(tex_eval(sc, tex, s));
+    f3 tn = normalize(tex_eval<FEAT>(sc, tex, s));
     f3 v = mk3(c0.x * tn.x + c1.x * tn.y + c2.x * tn.z, c0.y * tn.x + c1.y * tn.y + c2.y * tn.z, c0.z * tn.x + c1.z * tn.y + c2.z * tn.z);
     f3 ns = normalize(v);
     f3 ss = s.s_dpdu;
@@ -30,77 +31,81 @@ PT_HD void normal_mapping(const DScene &sc, int32_t tex, Surface &s) { // mod.rs
     s.ns = ns; s.s_dpdu = ss; s.s_dpdv = ts;
 }
 
-// returns false when the material yields no BSDF (glass with black r and t, Q17)
-PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, Bsdf &b) {
+// number of lobe slots per material kind (Disney: DisneyDiffuse + MicrofacetReflection)
+template <int MAT> struct MatLobes { static constexpr int N = (MAT == 4) ? 2 : 1; };
+
+// Material::compute_scattering_functions for the (compile-time) kind MAT of the innermost material.
+// Returns false when the material yields no BSDF (glass with black r and t, Q17).
+template <int MAT, int FEAT>
+PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, BsdfT<MatLobes<MAT>::N> &b) {
     DMaterial m = sc.mats[mat_id];
-    // NormalMaterial wraps another material (at most a few levels deep in practice)
-    for (int guard = 0; guard < 4 && m.kind == 6; ++guard) {
-        normal_mapping(sc, m.tex[0], s);
-        m = sc.mats[m.inner];
+    if (FEAT & FEAT_NORMAL) { // NormalMaterial wraps another material (mod.rs:136-141)
+        for (int guard = 0; guard < 4 && m.kind == 6; ++guard) {
+            normal_mapping<FEAT>(sc, m.tex[0], s);
+            m = sc.mats[m.inner];
+        }
     }
-    switch (m.kind) {
-        case 0: { // Matte
-            bsdf_init(b, s, 1.0f);
-            Lobe l = blank_lobe(LOBE_LAMBERT); l.r = tex_eval(sc, m.tex[0], s);
-            b.lobe[b.n++] = l;
-            return true;
+    if (MAT == 0) { // Matte, mod.rs:155-167
+        bsdf_init(b, s, 1.0f);
+        Lobe l = blank_lobe(LOBE_LAMBERT); l.r = tex_eval<FEAT>(sc, m.tex[0], s);
+        b.lobe[0] = l; b.n = 1;
+        return true;
+    } else if (MAT == 2) { // Mirror, mod.rs:180-195
+        bsdf_init(b, s, 1.0f);
+        Lobe l = blank_lobe(LOBE_SPEC_REFL); l.r = splat3(1.0f);
+        b.lobe[0] = l; b.n = 1;
+        return true;
+    } else if (MAT == 3) { // Glass, mod.rs:216-255
+        float eta = tex_eval<FEAT>(sc, m.tex[2], s).x;
+        f3 r = tex_eval<FEAT>(sc, m.tex[0], s), t = tex_eval<FEAT>(sc, m.tex[1], s);
+        bsdf_init(b, s, eta);
+        if (is_black(r) && is_black(t)) return false;
+        Lobe l = blank_lobe(LOBE_FRESNEL_SPEC); l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta;
+        b.lobe[0] = l; b.n = 1;
+        return true;
+    } else if (MAT == 1) { // Metal, metal.rs:49-94
+        bsdf_init(b, s, 1.0f);
+        float ur = m.tex[4] >= 0 ? tex_eval<FEAT>(sc, m.tex[4], s).x : tex_eval<FEAT>(sc, m.tex[3], s).x;
+        float vr = m.tex[5] >= 0 ? tex_eval<FEAT>(sc, m.tex[5], s).x : tex_eval<FEAT>(sc, m.tex[3], s).x;
+        if (m.flags & 1) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        Lobe l = blank_lobe(LOBE_MICRO_REFL); l.r = tex_eval<FEAT>(sc, m.tex[2], s);
+        set_tr(l, ur, vr, false);
+        l.fresnel = FR_CONDUCTOR; l.fa = tex_eval<FEAT>(sc, m.tex[0], s); l.fb = tex_eval<FEAT>(sc, m.tex[1], s);
+        b.lobe[0] = l; b.n = 1;
+        return true;
+    } else if (MAT == 5) { // Substrate, substrate.rs:42-68
+        bsdf_init(b, s, 1.0f);
+        f3 d = tex_eval<FEAT>(sc, m.tex[0], s), sp = tex_eval<FEAT>(sc, m.tex[1], s);
+        float ru = tex_eval<FEAT>(sc, m.tex[2], s).x, rv = tex_eval<FEAT>(sc, m.tex[3], s).x;
+        Lobe l = blank_lobe(LOBE_FRESNEL_BLEND);
+        if (!is_black(d) || is_black(sp)) { // Q20
+            if (m.flags & 1) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
+            l.r = d; l.t = sp; set_tr(l, ru, rv, false);
+            b.n = 1;
         }
-        case 2: { // Mirror
-            bsdf_init(b, s, 1.0f);
-            Lobe l = blank_lobe(LOBE_SPEC_REFL); l.r = splat3(1.0f);
-            b.lobe[b.n++] = l;
-            return true;
-        }
-        case 3: { // Glass
-            float eta = tex_eval(sc, m.tex[2], s).x;
-            f3 r = tex_eval(sc, m.tex[0], s), t = tex_eval(sc, m.tex[1], s);
-            bsdf_init(b, s, eta);
-            if (is_black(r) && is_black(t)) return false;
-            Lobe l = blank_lobe(LOBE_FRESNEL_SPEC); l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta;
-            b.lobe[b.n++] = l;
-            return true;
-        }
-        case 1: { // Metal
-            bsdf_init(b, s, 1.0f);
-            float ur = m.tex[4] >= 0 ? tex_eval(sc, m.tex[4], s).x : tex_eval(sc, m.tex[3], s).x;
-            float vr = m.tex[5] >= 0 ? tex_eval(sc, m.tex[5], s).x : tex_eval(sc, m.tex[3], s).x;
-            if (m.flags & 1) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
-            Lobe l = blank_lobe(LOBE_MICRO_REFL); l.r = tex_eval(sc, m.tex[2], s);
-            set_tr(l, ur, vr, false);
-            l.fresnel = FR_CONDUCTOR; l.fa = tex_eval(sc, m.tex[0], s); l.fb = tex_eval(sc, m.tex[1], s);
-            b.lobe[b.n++] = l;
-            return true;
-        }
-        case 5: { // Substrate
-            bsdf_init(b, s, 1.0f);
-            f3 d = tex_eval(sc, m.tex[0], s), sp = tex_eval(sc, m.tex[1], s);
-            float ru = tex_eval(sc, m.tex[2], s).x, rv = tex_eval(sc, m.tex[3], s).x;
-            if (!is_black(d) || is_black(sp)) { // Q20
-                if (m.flags & 1) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
-                Lobe l = blank_lobe(LOBE_FRESNEL_BLEND); l.r = d; l.t = sp; set_tr(l, ru, rv, false);
-                b.lobe[b.n++] = l;
-            }
-            return true;
-        }
-        default: { // Disney
-            bsdf_init(b, s, 1.0f);
-            f3 c = tex_eval(sc, m.tex[0], s);
-            float metallic = tex_eval(sc, m.tex[1], s).x, e = tex_eval(sc, m.tex[2], s).x;
-            float strans = 0.0f;
-            float diffuse_weight = (1.0f - metallic) * (1.0f - strans);
-            float rough = tex_eval(sc, m.tex[3], s).x;
-            float lum = luminance(c);
-            f3 c_tint = lum > 0.0f ? c / lum : splat3(1.0f);
-            if (diffuse_weight > 0.0f) { Lobe l = blank_lobe(LOBE_DISNEY_DIFFUSE); l.r = diffuse_weight * c; b.lobe[b.n++] = l; }
-            float aspect = 1.0f;
-            float ax = max_(0.001f, (rough * rough) / aspect), ay = max_(0.001f, (rough * rough) * aspect);
-            float r0s = ((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f)); // schlick_r0_from_eta
-            f3 spec0 = lerp3(r0s * lerp3(splat3(1.0f), c_tint, 0.0f), c, metallic);
-            Lobe l = blank_lobe(LOBE_MICRO_REFL); l.r = splat3(1.0f); set_tr(l, ax, ay, true);
-            l.fresnel = FR_DISNEY; l.fa = spec0; l.fb = mk3(metallic, e, 0.0f);
-            b.lobe[b.n++] = l;
-            return true;
-        }
+        b.lobe[0] = l;
+        return true;
+    } else { // Disney, disney.rs:172-264.  Slot 0 = DisneyDiffuse (only when diffuse_weight > 0), then MicrofacetReflection.
+        bsdf_init(b, s, 1.0f);
+        f3 c = tex_eval<FEAT>(sc, m.tex[0], s);
+        float metallic = tex_eval<FEAT>(sc, m.tex[1], s).x, e = tex_eval<FEAT>(sc, m.tex[2], s).x;
+        float strans = 0.0f;
+        float diffuse_weight = (1.0f - metallic) * (1.0f - strans);
+        float rough = tex_eval<FEAT>(sc, m.tex[3], s).x;
+        float lum = luminance(c);
+        f3 c_tint = lum > 0.0f ? c / lum : splat3(1.0f);
+        float aspect = 1.0f;
+        float ax = max_(0.001f, (rough * rough) / aspect), ay = max_(0.001f, (rough * rough) * aspect);
+        float r0s = ((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f)); // schlick_r0_from_eta
+        f3 spec0 = lerp3(r0s * lerp3(splat3(1.0f), c_tint, 0.0f), c, metallic);
+        Lobe ld = blank_lobe(LOBE_DISNEY_DIFFUSE); ld.r = diffuse_weight * c;
+        Lobe lm = blank_lobe(LOBE_MICRO_REFL); lm.r = splat3(1.0f); set_tr(lm, ax, ay, true);
+        lm.fresnel = FR_DISNEY; lm.fa = spec0; lm.fb = mk3(metallic, e, 0.0f);
+        // both slots have compile-time lobe kinds; with no diffuse lobe the container must behave as
+        // if the microfacet lobe were alone: give slot 0 a type that matches no query instead
+        b.lobe[0] = ld; b.lobe[1] = lm; b.n = 2;
+        if (!(diffuse_weight > 0.0f)) b.lobe[0].kind = LOBE_ABSENT;
+        return true;
     }
 }
 

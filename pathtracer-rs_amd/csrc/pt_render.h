@@ -5,7 +5,7 @@
 // sample rows x a block of sample indices, whose paths are all in flight at once (sized to use
 // HBM generously: ~300 bytes of state per path).  Within a pass the reference's per-path loop
 // (integrator.rs:406-500) becomes `max_depth + 1` rounds of
-//     trace(extension) -> sort -> shade[material] -> trace(shadow) -> trace(MIS) -> resolve
+//     extend (trace + bucketing) -> shade[material] -> connect (shadow / MIS queries + resolve)
 // and the film is updated once per pass by a deterministic gather.  The sampler ignores the tile
 // seed (sobol.rs:75-77), so the decomposition does not change any sample value (Q3).
 //
@@ -43,6 +43,20 @@ inline bool load_sobol_tables(const char *path, SobolTablesHost &T) {
     return ok;
 }
 
+// bytetab[dim][k][b] = XOR of SOBOL_MATRICES_32[dim*52 + 8k + j] over the set bits j of b (columns >= 52 do not exist: an
+// index never has those bits, 2m + log2(spp) <= 62 is checked by render_impl)
+inline void build_sobol_bytetab(const SobolTablesHost &T, std::vector<uint32_t> &out) {
+    out.assign((size_t)SOBOL_TAB_DIMS * 8 * 256, 0u);
+    for (uint32_t d = 0; d < (uint32_t)SOBOL_TAB_DIMS; ++d)
+        for (uint32_t k = 0; k < 8; ++k)
+            for (uint32_t b = 0; b < 256; ++b) {
+                uint32_t v = 0;
+                for (uint32_t j = 0; j < 8; ++j)
+                    if ((b >> j) & 1u) { uint32_t col = 8 * k + j; if (col < 52) v ^= T.matrices[(size_t)d * 52 + col]; }
+                out[((size_t)d * 8 + k) * 256 + b] = v;
+            }
+}
+
 inline int32_t round_up_pow2_i32(int32_t v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
 inline int64_t round_up_pow2_i64(int64_t v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v |= v >> 32; return v + 1; }
 
@@ -74,12 +88,19 @@ inline SampleGrid make_sample_grid(int32_t W, int32_t H, int32_t spp_in) {
     return g;
 }
 
-struct PassPlan { int32_t row0, row1; uint32_t s0, s1; };
+// FEAT_* bits (pt_texture.h) of a scene: only FEAT_SIMPLE (none) and FEAT_FULL (all) are instantiated
+inline int scene_features(const HostScene &H) {
+    bool any = !H.inf_lights.empty();
+    for (const DTexture &t : H.texs) any = any || t.kind == PTRS_TEX_IMAGE;
+    for (const DMaterial &m : H.mats) any = any || m.kind == PTRS_MAT_NORMAL;
+    return any ? FEAT_FULL : FEAT_SIMPLE;
+}
 
 template <class BE>
-int render_impl(BE &be, const DScene &sc, const bool kinds_present[7], uint32_t bvh_depth, const PtrsCamera &cam, const PtrsRenderParams &prm,
+int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_t bvh_depth, const PtrsCamera &cam, const PtrsRenderParams &prm,
                 v4 *film /* backend memory, W*H */, float *samples_out /* backend memory or null */, PtrsStats *stats, std::string &err) {
     using clock = std::chrono::steady_clock;
+    const bool *kinds_present = sc_host_feat.kinds_present;
     auto t_begin = clock::now();
     if (prm.width <= 0 || prm.height <= 0 || prm.spp <= 0 || prm.max_depth < 0) { err = "bad render parameters"; return PTRS_ERR_INVALID; }
     if (bvh_depth > 64) { err = "BVH deeper than the 64-entry traversal stack (accelerator.rs:370)"; return PTRS_ERR_UNSUPPORTED; }
@@ -92,7 +113,7 @@ int render_impl(BE &be, const DScene &sc, const bool kinds_present[7], uint32_t 
     const int32_t srow0 = std::max(rb, 0), srow1 = std::min(re + 4, g.NY);
 
     DSampler S;
-    S.matrices = be.sobol_matrices(); S.vdc = be.sobol_vdc(g.log2_res - 1); S.vdc_inv = be.sobol_vdc_inv(g.log2_res - 1);
+    S.matrices = be.sobol_matrices(); S.bytetab = be.sobol_bytetab(); S.vdc = be.sobol_vdc(g.log2_res - 1); S.vdc_inv = be.sobol_vdc_inv(g.log2_res - 1);
     S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
     DCamera C;
     std::memcpy(C.rot, cam.rot, 16); std::memcpy(C.trans, cam.trans, 12);
@@ -117,7 +138,8 @@ int render_impl(BE &be, const DScene &sc, const bool kinds_present[7], uint32_t 
 
     const uint32_t fixed_iters = (uint32_t)prm.max_depth + 1u; // li() runs at most max_depth+1 scene queries (Q7)
     const uint32_t max_iters = fixed_iters + 64u;              // head-room for null-BSDF skips (bounces -= 1)
-    int rc = be.begin(sc, S, C, (uint32_t)max_paths, max_iters + 1u, bvh_depth, prm.flags, err);
+    const int feat = scene_features(sc_host_feat);
+    int rc = be.begin(sc, S, C, (uint32_t)max_paths, max_iters + 1u, bvh_depth, prm.flags, feat, err);
     if (rc != PTRS_OK) return rc;
 
     PtrsStats st;
@@ -133,12 +155,9 @@ int render_impl(BE &be, const DScene &sc, const bool kinds_present[7], uint32_t 
             be.generate();
             uint32_t it = 0;
             auto round = [&](uint32_t i) {
-                be.trace_extension(i);
-                be.sort(i);
-                for (int k = 0; k < 7; ++k) if (kinds_present[k]) be.shade(i, k);
-                be.trace_shadow(i);
-                be.trace_mis(i);
-                be.resolve(i);
+                be.extend(i);                                                     // closest hit + emission / miss / depth cut + material buckets
+                for (int k = 0; k < 6; ++k) if (kinds_present[k]) be.shade(i, k); // one specialised kernel per material bucket
+                be.connect(i);                                                    // shadow + MIS queries, resolve into L
             };
             for (; it < fixed_iters; ++it) round(it);
             // A path can outlive max_depth+1 rounds only through null-BSDF skips (`bounces -= 1`,

@@ -76,8 +76,11 @@ struct DScene {
     uint32_t n_nodes, n_prims, n_lights, n_inf;
 };
 
+enum { SOBOL_TAB_DIMS = 256 };
+
 struct DSampler { // SobolSamplerBuilder::new (sobol.rs:35-60) + table rows
     const uint32_t *matrices; // [1024*52]
+    const uint32_t *bytetab;  // optional [SOBOL_TAB_DIMS][8][256]: XOR of the matrix columns selected by one index byte
     const uint64_t *vdc;      // row m-1 of VD_C_SOBOL_MATRICES
     const uint64_t *vdc_inv;  // row m-1 of VD_C_SOBOL_MATRICES_INV
     uint32_t log2_res;
@@ -130,8 +133,6 @@ struct DPaths {
     v4 *sh_d;   // shadow ray d.xyz
     v4 *mis_o;  // MIS ray o.xyz
     v4 *mis_d;  // MIS ray d.xyz
-    u4 *mis_hit;
-    uint32_t *sh_res; // 1 = occluded
 };
 
 // queue counters: one row of uint32 per loop iteration
@@ -141,7 +142,7 @@ enum { CNT_EXT = 0, CNT_SHADOW = 1, CNT_MIS = 2, CNT_NODES = 3, CNT_TRIS = 4, CN
 struct DQueues {
     uint32_t *ext[2];          // ping-pong extension-ray queues
     uint32_t *mat[Q_NUM_MAT];  // one shade queue per material kind
-    uint32_t *shadow, *mis, *nee;
+    uint32_t *nee;             // paths with a pending next-event-estimation record this round
     uint32_t *counts;          // [iters][Q_STRIDE]
     unsigned long long *stats; // [CNT_NUM]
 };

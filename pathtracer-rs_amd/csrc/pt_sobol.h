@@ -25,12 +25,22 @@ PT_HD uint32_t pixel_scramble(int32_t x, int32_t y) {
     return (uint32_t)((a + b) * (a + b + 1) / 2 + b);
 }
 
-// sobol_sample (lowdiscrepancy.rs:42-57)
+// sobol_sample (lowdiscrepancy.rs:42-57).  v = scramble XOR (XOR of matrix columns at the set bits
+// of index).  XOR is associative, so the columns are pre-combined per index byte
+// (bytetab[dim][k][b] = XOR_{j in bits(b)} M[dim][8k+j]); the result is bit-identical to the
+// bit-serial loop, which remains as the fallback for dimensions beyond the table.
 PT_HD float sobol_sample(const DSampler &S, uint64_t index, uint32_t dim, uint32_t scramble) {
     uint32_t v = scramble;
-    const uint32_t *mat = S.matrices + dim * 52u;
-    for (; index != 0; index >>= 1, ++mat)
-        if (index & 1) v ^= *mat;
+    if (S.bytetab && dim < (uint32_t)SOBOL_TAB_DIMS) {
+        const uint32_t *t = S.bytetab + (size_t)dim * (8u * 256u);
+        uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+        v ^= t[lo & 255u] ^ t[256u + ((lo >> 8) & 255u)] ^ t[512u + ((lo >> 16) & 255u)] ^ t[768u + (lo >> 24)];
+        if (hi) v ^= t[1024u + (hi & 255u)] ^ t[1280u + ((hi >> 8) & 255u)] ^ t[1536u + ((hi >> 16) & 255u)] ^ t[1792u + (hi >> 24)];
+    } else {
+        const uint32_t *mat = S.matrices + dim * 52u;
+        for (; index != 0; index >>= 1, ++mat)
+            if (index & 1) v ^= *mat;
+    }
     return min_(PT_ONE_MINUS_EPS, (float)v * 0x1p-32f);
 }
 

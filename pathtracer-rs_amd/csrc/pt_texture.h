@@ -6,6 +6,11 @@
 
 namespace pt {
 
+// Compile-time feature set of a scene (selects kernel instantiations; never changes a value):
+//   FEAT_IMAGE   image textures present (MIP lookups)      FEAT_INFINITE  environment light present
+//   FEAT_NORMAL  NormalMaterial wrappers present
+enum : int { FEAT_IMAGE = 1, FEAT_INFINITE = 2, FEAT_NORMAL = 4, FEAT_SIMPLE = 0, FEAT_FULL = 7 };
+
 PT_HD f3 tex_texel(const DScene &sc, const DTexture &T, uint32_t level, int32_t s, int32_t t) {
     const DTexLevel L = sc.levels[T.first_level + level];
     if (T.wrap == 0) { s = abs_mod(s, L.cols); t = abs_mod(t, L.rows); }
@@ -38,6 +43,7 @@ PT_HD f3 tex_lookup_width(const DScene &sc, const DTexture &T, f2 st, float widt
 }
 
 // Texture::evaluate; 1-channel textures return their value in .x
+template <int FEAT>
 PT_HD f3 tex_eval(const DScene &sc, int32_t id, f2 uv, float dudx, float dvdx, float dudy, float dvdy) {
     const DTexture &T = sc.texs[id];
     if (T.kind == 0) return mk3(T.value[0], T.value[1], T.value[2]);
@@ -47,10 +53,12 @@ PT_HD f3 tex_eval(const DScene &sc, int32_t id, f2 uv, float dudx, float dvdx, f
         bool second = (si <= 0.5f && ti <= 0.5f) || (si >= 0.5f && ti >= 0.5f);
         return second ? mk3(T.value2[0], T.value2[1], T.value2[2]) : mk3(T.value[0], T.value[1], T.value[2]);
     }
+    if (!(FEAT & FEAT_IMAGE)) return splat3(0.0f); // unreachable: the scene has no image texture
     float dx0 = T.su * dudx, dx1 = T.sv * dvdx, dy0 = T.su * dudy, dy1 = T.sv * dvdy;
     float width = max_(max_(fabs_(dx0), fabs_(dx1)), max_(fabs_(dy0), fabs_(dy1)));
     return tex_lookup_width(sc, T, st, width);
 }
-PT_HD f3 tex_eval(const DScene &sc, int32_t id, const Surface &s) { return tex_eval(sc, id, s.uv, s.dudx, s.dvdx, s.dudy, s.dvdy); }
+template <int FEAT>
+PT_HD f3 tex_eval(const DScene &sc, int32_t id, const Surface &s) { return tex_eval<FEAT>(sc, id, s.uv, s.dudx, s.dvdx, s.dudy, s.dvdy); }
 
 } // namespace pt

@@ -57,6 +57,7 @@ struct LdsStack { // column `threadIdx.x` of a [depth][BLOCK] LDS array
     __device__ inline void push(uint32_t v) { col[n * BLOCK] = v; ++n; }
     __device__ inline uint32_t pop() { --n; return col[n * BLOCK]; }
     __device__ inline bool empty() const { return n == 0; }
+    __device__ inline void clear() { n = 0; }
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
@@ -90,47 +91,73 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const uint32_t *__re
     if (counters_on) { atomicAdd(&stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&stats[CNT_TRIS], (unsigned long long)nt); }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_sort(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask) {
-    const uint32_t *queue = Q.ext[it & 1u];
+// Extension rays: closest-hit traversal, then the epilogue of integrator.rs:418-431 and the
+// wavefront-ballot bucketing of surviving paths by material kind (one ballot + one atomic per wave
+// and bucket).
+template <int FEAT, int DEPTH>
+__global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask) {
+    __shared__ uint32_t lds_stack[DEPTH * BLOCK];
+    const uint32_t *__restrict__ queue = Q.ext[it & 1u];
     uint32_t *counts = Q.counts + (size_t)it * Q_STRIDE;
     const uint32_t n = counts[Q_EXT];
     const uint32_t stride = gridDim.x * BLOCK;
+    uint32_t nn = 0, nt = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const uint32_t pid = queue[i];
-        const int k = sort_item(R, sc, P, pid);
-        for (int m = 0; m < Q_NUM_MAT; ++m) { // wavefront-ballot material bucketing
+        const v4 o = P.ray_o[pid], d = P.ray_d[pid];
+        LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
+        HitRec h;
+        bvh_trace<false>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+        u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
+        P.hit[pid] = r;
+        const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
+        for (int m = 0; m < 6; ++m) {
             if (!(kinds_mask & (1u << m))) continue;
             const uint32_t slot = wave_push(&counts[Q_MAT0 + m], k == m);
             if (k == m) Q.mat[m][slot] = pid;
         }
     }
+    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, int kind) {
-    const uint32_t *queue = Q.mat[kind];
+__device__ inline void wave_count(uint32_t *counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m != 0ull && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(counter, (uint32_t)__popcll(m));
+}
+
+// One instantiation per material kind (and feature set): lobe kinds are compile-time constants.
+template <int MAT, int FEAT>
+__global__ __launch_bounds__(BLOCK) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it) {
+    const uint32_t *__restrict__ queue = Q.mat[MAT];
     uint32_t *counts = Q.counts + (size_t)it * Q_STRIDE;
     uint32_t *next_count = Q.counts + (size_t)(it + 1u) * Q_STRIDE + Q_EXT;
     uint32_t *next = Q.ext[(it + 1u) & 1u];
-    const uint32_t n = counts[Q_MAT0 + kind];
+    const uint32_t n = counts[Q_MAT0 + MAT];
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const uint32_t pid = queue[i];
-        const ShadeResult r = shade_item(R, S, C, sc, P, pid);
+        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid);
         uint32_t slot = wave_push(next_count, r.next);
         if (r.next) next[slot] = pid;
-        slot = wave_push(&counts[Q_SHADOW], r.shadow);
-        if (r.shadow) Q.shadow[slot] = pid;
-        slot = wave_push(&counts[Q_MIS], r.mis);
-        if (r.mis) Q.mis[slot] = pid;
         slot = wave_push(&counts[Q_NEE], r.nee);
         if (r.nee) Q.nee[slot] = pid;
+        wave_count(&counts[Q_SHADOW], r.shadow);
+        wave_count(&counts[Q_MIS], r.mis);
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues Q, uint32_t it) {
+// Shadow (any-hit) and MIS (closest-hit) queries of the pending NEE records, resolved into L.
+template <int FEAT, int DEPTH>
+__global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it) {
+    __shared__ uint32_t lds_stack[DEPTH * BLOCK];
     const uint32_t n = Q.counts[(size_t)it * Q_STRIDE + Q_NEE];
     const uint32_t stride = gridDim.x * BLOCK;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) resolve_item(sc, P, Q.nee[i]);
+    uint32_t nn = 0, nt = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
+        connect_item<FEAT>(sc, P, Q.nee[i], stk, nn, nt);
+    }
+    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P, const float *__restrict__ table, v4 *film, int32_t y0, int32_t y1) {
@@ -187,7 +214,7 @@ template <class T> int upload(DevBuf &b, const std::vector<T> &v) {
 
 struct SobolDevice { // one copy per device
     int device = -1;
-    DevBuf matrices, vdc, vdc_inv;
+    DevBuf matrices, vdc, vdc_inv, bytetab;
     uint32_t stride = 52;
 };
 std::mutex g_mu;
@@ -207,6 +234,12 @@ int get_sobol(int device, SobolDevice **out) {
     HIPCHK(hipMemcpy(s->matrices.p, pm, nmat * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->vdc.p, pv, (size_t)hdr[2] * stride * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->vdc_inv.p, pvi, (size_t)hdr[3] * stride * 8, hipMemcpyHostToDevice));
+    {
+        SobolTablesHost T; T.matrices.resize(nmat); std::memcpy(T.matrices.data(), pm, nmat * 4);
+        std::vector<uint32_t> bt; build_sobol_bytetab(T, bt);
+        if ((rc = s->bytetab.ensure(bt.size() * 4)) != PTRS_OK) { delete s; return rc; }
+        HIPCHK(hipMemcpy(s->bytetab.p, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
+    }
     g_sobol.push_back(s);
     *out = s;
     return PTRS_OK;
@@ -237,6 +270,7 @@ struct HipBackend {
     PtrsScene *ps; hipStream_t stream; SobolDevice *sob;
     DScene sc; DSampler S; DCamera C; DParams R; DPaths P; DQueues Q;
     uint32_t cap = 0, rows = 0, depth = 0, flags = 0, kinds_mask = 0;
+    int feat = FEAT_FULL;
     int grid_max = 2048;
     int rc = PTRS_OK;
     // timing
@@ -245,6 +279,7 @@ struct HipBackend {
     uint64_t launches = 0, trace_launches = 0;
 
     const uint32_t *sobol_matrices() { return (const uint32_t *)sob->matrices.p; }
+    const uint32_t *sobol_bytetab() { return (const uint32_t *)sob->bytetab.p; }
     const uint64_t *sobol_vdc(uint32_t row) { return (const uint64_t *)sob->vdc.p + (size_t)row * sob->stride; }
     const uint64_t *sobol_vdc_inv(uint32_t row) { return (const uint64_t *)sob->vdc_inv.p + (size_t)row * sob->stride; }
 
@@ -256,16 +291,16 @@ struct HipBackend {
     void t1() { if (flags & PTRS_FLAG_TIMING) { if (spans.back().b) (void)hipEventRecord(spans.back().b, stream); } }
     int grid_for(uint32_t n) const { uint32_t g = (n + BLOCK - 1) / BLOCK; if (g < 1) g = 1; return (int)(g > (uint32_t)grid_max ? (uint32_t)grid_max : g); }
 
-    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, std::string &err) {
-        sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_;
+    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, std::string &err) {
+        sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_;
         grid_max = ps->n_cu * 8;
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = (size_t)cap * 4;
         void **slots16[] = {(void **)&P.ray_o, (void **)&P.ray_d, (void **)&P.beta, (void **)&P.L, (void **)&P.st, (void **)&P.hit, (void **)&P.pfilm, (void **)&P.nee0,
-                            (void **)&P.nee1, (void **)&P.nee2, (void **)&P.sh_o, (void **)&P.sh_d, (void **)&P.mis_o, (void **)&P.mis_d, (void **)&P.mis_hit};
+                            (void **)&P.nee1, (void **)&P.nee2, (void **)&P.sh_o, (void **)&P.sh_d, (void **)&P.mis_o, (void **)&P.mis_d};
         int w = 0;
         for (auto s : slots16) { if ((rc = ps->ws[w].ensure(n16)) != PTRS_OK) { err = g_err; return rc; } *s = ps->ws[w++].p; }
-        void **slots4[] = {(void **)&P.sh_res, (void **)&Q.ext[0], (void **)&Q.ext[1], (void **)&Q.shadow, (void **)&Q.mis, (void **)&Q.nee};
+        void **slots4[] = {(void **)&Q.ext[0], (void **)&Q.ext[1], (void **)&Q.nee};
         for (auto s : slots4) { if ((rc = ps->ws[w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } *s = ps->ws[w++].p; }
         for (int k = 0; k < Q_NUM_MAT; ++k) {
             Q.mat[k] = nullptr;
@@ -281,21 +316,33 @@ struct HipBackend {
     void pass_begin(const DParams &R_) { R = R_; (void)hipMemsetAsync(Q.counts, 0, (size_t)rows * Q_STRIDE * 4, stream); }
     void generate() { t0(1); hipLaunchKernelGGL(k_generate, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, C, P, Q.ext[0], Q.counts + Q_EXT); t1(); }
 
-    template <bool ANY> void launch_trace(const uint32_t *queue, const uint32_t *count, const v4 *ro, const v4 *rd, u4 *hits, uint32_t *occl, uint32_t n_upper) {
-        t0(0);
-        dim3 g(grid_for(n_upper)), b(BLOCK);
-        if (depth <= 16) hipLaunchKernelGGL((k_trace<ANY, 16>), g, b, 0, stream, sc, queue, count, ro, rd, hits, occl, (float *)nullptr, Q.stats, R.counters_on);
-        else if (depth <= 32) hipLaunchKernelGGL((k_trace<ANY, 32>), g, b, 0, stream, sc, queue, count, ro, rd, hits, occl, (float *)nullptr, Q.stats, R.counters_on);
-        else hipLaunchKernelGGL((k_trace<ANY, 64>), g, b, 0, stream, sc, queue, count, ro, rd, hits, occl, (float *)nullptr, Q.stats, R.counters_on);
-        t1();
-    }
     uint32_t *cnt(uint32_t it, int q) { return Q.counts + (size_t)it * Q_STRIDE + q; }
-    void trace_extension(uint32_t it) { launch_trace<false>(Q.ext[it & 1u], cnt(it, Q_EXT), P.ray_o, P.ray_d, P.hit, nullptr, R.n_paths); }
-    void trace_shadow(uint32_t it) { launch_trace<true>(Q.shadow, cnt(it, Q_SHADOW), P.sh_o, P.sh_d, nullptr, P.sh_res, R.n_paths); }
-    void trace_mis(uint32_t it) { launch_trace<false>(Q.mis, cnt(it, Q_MIS), P.mis_o, P.mis_d, P.mis_hit, nullptr, R.n_paths); }
-    void sort(uint32_t it) { t0(1); hipLaunchKernelGGL(k_sort, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, sc, P, Q, it, kinds_mask); t1(); }
-    void shade(uint32_t it, int kind) { t0(1); hipLaunchKernelGGL(k_shade, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, C, sc, P, Q, it, kind); t1(); }
-    void resolve(uint32_t it) { t0(1); hipLaunchKernelGGL(k_resolve, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, sc, P, Q, it); t1(); }
+    template <int FEAT> void extend_t(uint32_t it) {
+        dim3 g(grid_for(R.n_paths)), b(BLOCK);
+        if (depth <= 16) hipLaunchKernelGGL((k_extend<FEAT, 16>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask);
+        else if (depth <= 32) hipLaunchKernelGGL((k_extend<FEAT, 32>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask);
+        else hipLaunchKernelGGL((k_extend<FEAT, 64>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask);
+    }
+    void extend(uint32_t it) { t0(0); if (feat == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
+    template <int FEAT> void connect_t(uint32_t it) {
+        dim3 g(grid_for(R.n_paths)), b(BLOCK);
+        if (depth <= 16) hipLaunchKernelGGL((k_connect<FEAT, 16>), g, b, 0, stream, R, sc, P, Q, it);
+        else if (depth <= 32) hipLaunchKernelGGL((k_connect<FEAT, 32>), g, b, 0, stream, R, sc, P, Q, it);
+        else hipLaunchKernelGGL((k_connect<FEAT, 64>), g, b, 0, stream, R, sc, P, Q, it);
+    }
+    void connect(uint32_t it) { t0(0); if (feat == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
+    template <int FEAT> void shade_t(uint32_t it, int kind) {
+        dim3 g(grid_for(R.n_paths)), b(BLOCK);
+        switch (kind) {
+            case 0: hipLaunchKernelGGL((k_shade<0, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
+            case 1: hipLaunchKernelGGL((k_shade<1, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
+            case 2: hipLaunchKernelGGL((k_shade<2, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
+            case 3: hipLaunchKernelGGL((k_shade<3, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
+            case 4: hipLaunchKernelGGL((k_shade<4, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
+            default: hipLaunchKernelGGL((k_shade<5, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
+        }
+    }
+    void shade(uint32_t it, int kind) { t0(1); if (feat == FEAT_FULL) shade_t<FEAT_FULL>(it, kind); else shade_t<FEAT_SIMPLE>(it, kind); t1(); }
     uint32_t read_count(uint32_t it, int q) { uint32_t v = 0; (void)hipMemcpyAsync(&v, cnt(it, q), 4, hipMemcpyDeviceToHost, stream); (void)hipStreamSynchronize(stream); return v; }
     void read_counts(uint32_t *dst, uint32_t n_rows) { (void)hipMemcpyAsync(dst, Q.counts, (size_t)n_rows * Q_STRIDE * 4, hipMemcpyDeviceToHost, stream); if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE; }
     void film(v4 *film_px, int32_t y0, int32_t y1) { t0(2); hipLaunchKernelGGL(k_film, dim3(grid_for((uint32_t)(y1 - y0) * (uint32_t)R.W)), dim3(BLOCK), 0, stream, R, S, P, (const float *)ps->table.p, film_px, y0, y1); t1(); }
@@ -326,7 +373,7 @@ int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm,
     int rc = get_sobol(ps->device, &be.sob);
     if (rc != PTRS_OK) return rc;
     std::string err;
-    rc = render_impl(be, ps->sc, ps->H.kinds_present, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err);
+    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err);
     if (rc != PTRS_OK) { if (!err.empty()) g_err = err; return rc; }
     if (be.rc != PTRS_OK) { if (g_err.empty()) g_err = "device error during render"; return be.rc; }
     return PTRS_OK;
@@ -506,7 +553,7 @@ int ptrs_sobol_samples(const PtrsRenderParams *params, uint32_t n, const int32_t
     int rc = get_sobol(params->device, &sob);
     if (rc != PTRS_OK) return rc;
     DSampler S;
-    S.matrices = (const uint32_t *)sob->matrices.p; S.vdc = (const uint64_t *)sob->vdc.p + (size_t)(g.log2_res - 1) * sob->stride; S.vdc_inv = (const uint64_t *)sob->vdc_inv.p + (size_t)(g.log2_res - 1) * sob->stride;
+    S.matrices = (const uint32_t *)sob->matrices.p; S.bytetab = (const uint32_t *)sob->bytetab.p; S.vdc = (const uint64_t *)sob->vdc.p + (size_t)(g.log2_res - 1) * sob->stride; S.vdc_inv = (const uint64_t *)sob->vdc_inv.p + (size_t)(g.log2_res - 1) * sob->stride;
     S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
     DevBuf bx, by, bn, bdm, bo, bi;
     auto cleanup = [&]() { bx.release(); by.release(); bn.release(); bdm.release(); bo.release(); bi.release(); };

@@ -17,34 +17,52 @@ namespace {
 
 thread_local std::string g_err;
 SobolTablesHost g_tables;
+std::vector<uint32_t> g_bytetab;
+bool g_use_bytetab = true;
+bool g_force_full = false;
 
 struct TwinScene {
     HostScene H;
     DScene sc;
 };
 
+// traversal stack with the capacity the GPU kernel would get (16 / 32 / 64 LDS entries) and an
+// overflow flag, so that a stack misuse shows up on the CPU instead of corrupting LDS on the GPU
+struct CheckedStack {
+    uint32_t s[64]; int n = 0; int cap = 64; bool *overflow = nullptr;
+    void push(uint32_t v) { if (n >= cap) { if (overflow) *overflow = true; return; } s[n++] = v; }
+    uint32_t pop() { return s[--n]; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+};
+
 struct HostBackend {
+    bool overflow = false; int stack_cap = 64;
+    CheckedStack make_stack() { CheckedStack k; k.cap = stack_cap; k.overflow = &overflow; return k; }
     DScene sc; DSampler S; DCamera C; DParams R; DPaths P; DQueues Q;
     std::vector<std::vector<unsigned char>> pool;
     float table[256];
     uint32_t cap = 0, rows = 0;
+    int feat = FEAT_FULL;
     uint64_t nodes = 0, tris = 0;
 
     const uint32_t *sobol_matrices() { return g_tables.matrices.data(); }
+    const uint32_t *sobol_bytetab() { return g_use_bytetab ? g_bytetab.data() : nullptr; }
     const uint64_t *sobol_vdc(uint32_t row) { return g_tables.vdc.data() + (size_t)row * g_tables.stride; }
     const uint64_t *sobol_vdc_inv(uint32_t row) { return g_tables.vdc_inv.data() + (size_t)row * g_tables.stride; }
 
     template <class T> T *alloc(size_t n) { pool.emplace_back(n * sizeof(T) + 64); return reinterpret_cast<T *>(pool.back().data()); }
 
-    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t, uint32_t, std::string &) {
-        sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows;
+    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t, int feat_, std::string &) {
+        stack_cap = bvh_depth <= 16 ? 16 : (bvh_depth <= 32 ? 32 : 64);
+        sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; feat = g_force_full ? FEAT_FULL : feat_;
         gaussian_filter_table(table);
         P.ray_o = alloc<v4>(cap); P.ray_d = alloc<v4>(cap); P.beta = alloc<v4>(cap); P.L = alloc<v4>(cap); P.st = alloc<u4>(cap); P.hit = alloc<u4>(cap);
         P.pfilm = alloc<v4>(cap); P.nee0 = alloc<v4>(cap); P.nee1 = alloc<v4>(cap); P.nee2 = alloc<u4>(cap); P.sh_o = alloc<v4>(cap); P.sh_d = alloc<v4>(cap);
-        P.mis_o = alloc<v4>(cap); P.mis_d = alloc<v4>(cap); P.mis_hit = alloc<u4>(cap); P.sh_res = alloc<uint32_t>(cap);
+        P.mis_o = alloc<v4>(cap); P.mis_d = alloc<v4>(cap);
         Q.ext[0] = alloc<uint32_t>(cap); Q.ext[1] = alloc<uint32_t>(cap);
         for (int k = 0; k < Q_NUM_MAT; ++k) Q.mat[k] = alloc<uint32_t>(cap);
-        Q.shadow = alloc<uint32_t>(cap); Q.mis = alloc<uint32_t>(cap); Q.nee = alloc<uint32_t>(cap);
+        Q.nee = alloc<uint32_t>(cap);
         Q.counts = alloc<uint32_t>((size_t)rows * Q_STRIDE); Q.stats = alloc<unsigned long long>(CNT_NUM);
         return PTRS_OK;
     }
@@ -54,40 +72,39 @@ struct HostBackend {
         for (uint32_t pid = 0; pid < R.n_paths; ++pid) { generate_item(R, S, C, P, pid); Q.ext[0][pid] = pid; }
         cnt(0, Q_EXT) = R.n_paths;
     }
-    template <bool ANY> void trace(const uint32_t *queue, uint32_t n, const v4 *ro, const v4 *rd, u4 *hits, uint32_t *occl) {
-        for (uint32_t i = 0; i < n; ++i) {
-            uint32_t pid = queue[i];
-            v4 o = ro[pid], d = rd[pid];
-            LocalStack stk; HitRec h; uint32_t nn = 0, nt = 0;
-            bool hit = bvh_trace<ANY>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
-            nodes += nn; tris += nt;
-            if (ANY) occl[pid] = hit ? 1u : 0u;
-            else { u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); hits[pid] = r; }
-        }
-    }
-    void trace_extension(uint32_t it) { trace<false>(Q.ext[it & 1], cnt(it, Q_EXT), P.ray_o, P.ray_d, P.hit, nullptr); }
-    void trace_shadow(uint32_t it) { trace<true>(Q.shadow, cnt(it, Q_SHADOW), P.sh_o, P.sh_d, nullptr, P.sh_res); }
-    void trace_mis(uint32_t it) { trace<false>(Q.mis, cnt(it, Q_MIS), P.mis_o, P.mis_d, P.mis_hit, nullptr); }
-    void sort(uint32_t it) {
+    template <int FEAT> void extend_t(uint32_t it) {
         const uint32_t *q = Q.ext[it & 1];
         for (uint32_t i = 0, n = cnt(it, Q_EXT); i < n; ++i) {
-            int k = sort_item(R, sc, P, q[i]);
-            if (k >= 0) Q.mat[k][cnt(it, Q_MAT0 + k)++] = q[i];
+            const uint32_t pid = q[i];
+            const v4 o = P.ray_o[pid], d = P.ray_d[pid];
+            CheckedStack stk = make_stack(); HitRec h; uint32_t nn = 0, nt = 0;
+            bvh_trace<false>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+            nodes += nn; tris += nt;
+            u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
+            const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
+            if (k >= 0) Q.mat[k][cnt(it, Q_MAT0 + k)++] = pid;
         }
     }
+    void extend(uint32_t it) { if (feat == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); }
     void shade(uint32_t it, int kind) {
         const uint32_t *q = Q.mat[kind];
         uint32_t *next = Q.ext[(it + 1) & 1];
         for (uint32_t i = 0, n = cnt(it, Q_MAT0 + kind); i < n; ++i) {
-            uint32_t pid = q[i];
-            ShadeResult r = shade_item(R, S, C, sc, P, pid);
+            const uint32_t pid = q[i];
+            const ShadeResult r = feat == FEAT_FULL ? shade_dispatch<FEAT_FULL>(kind, R, S, C, sc, P, pid) : shade_dispatch<FEAT_SIMPLE>(kind, R, S, C, sc, P, pid);
             if (r.next) next[cnt(it + 1, Q_EXT)++] = pid;
-            if (r.shadow) Q.shadow[cnt(it, Q_SHADOW)++] = pid;
-            if (r.mis) Q.mis[cnt(it, Q_MIS)++] = pid;
+            if (r.shadow) cnt(it, Q_SHADOW)++;
+            if (r.mis) cnt(it, Q_MIS)++;
             if (r.nee) Q.nee[cnt(it, Q_NEE)++] = pid;
         }
     }
-    void resolve(uint32_t it) { for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) resolve_item(sc, P, Q.nee[i]); }
+    void connect(uint32_t it) {
+        for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) {
+            CheckedStack stk = make_stack(); uint32_t nn = 0, nt = 0;
+            if (feat == FEAT_FULL) connect_item<FEAT_FULL>(sc, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE>(sc, P, Q.nee[i], stk, nn, nt);
+            nodes += nn; tris += nt;
+        }
+    }
     uint32_t read_count(uint32_t it, int q) { return cnt(it, q); }
     void read_counts(uint32_t *dst, uint32_t n_rows) { std::memcpy(dst, Q.counts, (size_t)n_rows * Q_STRIDE * 4); }
     void film(v4 *film_px, int32_t y0, int32_t y1) {
@@ -100,7 +117,7 @@ struct HostBackend {
             out[o] = P.L[pid].x; out[o + 1] = P.L[pid].y; out[o + 2] = P.L[pid].z;
         }
     }
-    void end(PtrsStats &st) { st.nodes_visited = nodes; st.tris_tested = tris; }
+    void end(PtrsStats &st) { st.nodes_visited = nodes; st.tris_tested = tris; if (overflow) st.kernel_launches = 0xdeadull; }
 };
 
 } // namespace
@@ -108,7 +125,13 @@ struct HostBackend {
 extern "C" {
 
 const char *twin_last_error(void) { return g_err.c_str(); }
-int twin_load_tables(const char *path) { return load_sobol_tables(path, g_tables) ? PTRS_OK : PTRS_ERR_IO; }
+int twin_load_tables(const char *path) {
+    if (!load_sobol_tables(path, g_tables)) return PTRS_ERR_IO;
+    build_sobol_bytetab(g_tables, g_bytetab);
+    return PTRS_OK;
+}
+void twin_use_bytetab(int on) { g_use_bytetab = on != 0; }
+void twin_force_full_features(int on) { g_force_full = on != 0; }
 
 int twin_scene_create(const PtrsSceneDesc *d, void **out) {
     auto *s = new TwinScene();
@@ -127,7 +150,9 @@ int twin_render(void *sp, const PtrsCamera *cam, const PtrsRenderParams *prm, Pt
     if (!g_tables.ok) { g_err = "tables not loaded"; return PTRS_ERR_INVALID; }
     TwinScene *s = static_cast<TwinScene *>(sp);
     HostBackend be;
-    return render_impl(be, s->sc, s->H.kinds_present, s->H.max_depth, *cam, *prm, reinterpret_cast<v4 *>(film), sample_rgb, stats, g_err);
+    int rc = render_impl(be, s->sc, s->H, s->H.max_depth, *cam, *prm, reinterpret_cast<v4 *>(film), sample_rgb, stats, g_err);
+    if (rc == PTRS_OK && be.overflow) { g_err = "traversal stack overflow (would corrupt LDS on the GPU)"; return PTRS_ERR_INVALID; }
+    return rc;
 }
 
 int twin_trace_rays(void *sp, uint32_t n, const float *rays, int32_t any_hit, PtrsHit *hits, PtrsStats *stats) {
@@ -148,7 +173,7 @@ int twin_sobol_samples(const PtrsRenderParams *prm, uint32_t n, const int32_t *p
     if (!g_tables.ok) { g_err = "tables not loaded"; return PTRS_ERR_INVALID; }
     SampleGrid g = make_sample_grid(prm->width, prm->height, prm->spp);
     DSampler S;
-    S.matrices = g_tables.matrices.data(); S.vdc = g_tables.vdc.data() + (size_t)(g.log2_res - 1) * g_tables.stride; S.vdc_inv = g_tables.vdc_inv.data() + (size_t)(g.log2_res - 1) * g_tables.stride;
+    S.matrices = g_tables.matrices.data(); S.bytetab = g_use_bytetab ? g_bytetab.data() : nullptr; S.vdc = g_tables.vdc.data() + (size_t)(g.log2_res - 1) * g_tables.stride; S.vdc_inv = g_tables.vdc_inv.data() + (size_t)(g.log2_res - 1) * g_tables.stride;
     S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
     for (uint32_t i = 0; i < n; ++i) {
         uint64_t idx = sobol_index(S, sample_nums[i], (uint32_t)(px[i] - g.min_x), (uint32_t)(py[i] - g.min_y));
