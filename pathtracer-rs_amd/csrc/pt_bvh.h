@@ -10,7 +10,7 @@
 
 namespace pt {
 
-struct HitRec { int32_t prim; float t, b0, b1, b2; };
+struct HitRec { int32_t prim; float t, b0, b1, b2; uint32_t flags; };
 
 PT_HD bool slab_test(const v4 &a, const v4 &b, f3 o, f3 inv, const bool neg[3], float t_max) {
     // a = (pmin.xyz, pmax.x)   b = (pmax.y, pmax.z, offset, meta)
@@ -35,12 +35,19 @@ PT_HD bool slab_test(const v4 &a, const v4 &b, f3 o, f3 inv, const bool neg[3], 
     return (t_min < t_max) && (t_mx > 0.0f);
 }
 
-PT_HD void load_tri(const DTri *tris, uint32_t k, f3 &p0, f3 &p1, f3 &p2, uint32_t &prim, uint32_t &flags) {
-    const v4 *q = reinterpret_cast<const v4 *>(tris + k);
-    v4 a = q[0], b = q[1], c = q[2];
-    p0 = mk3(a.x, a.y, a.z); p1 = mk3(a.w, b.x, b.y); p2 = mk3(b.z, b.w, c.x);
-    prim = f2u(c.y); flags = f2u(c.z);
-}
+// Where traversal reads geometry from.  GeomGlobal: the HBM arrays (through L1/L2).  GeomLocal:
+// a 16-byte-vector copy [2 per node | 3 per triangle] -- on gfx950 the kernels stage small scenes
+// (Cornell: 59 nodes + 36 triangles = 3.6 KB) into LDS once per workgroup and walk them there.
+struct GeomGlobal {
+    const DNode *nodes; const DTri *tris;
+    PT_MEM void node(uint32_t i, v4 &a, v4 &b) const { const v4 *q = reinterpret_cast<const v4 *>(nodes + i); a = q[0]; b = q[1]; }
+    PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { const v4 *q = reinterpret_cast<const v4 *>(tris + k); a = q[0]; b = q[1]; c = q[2]; }
+};
+struct GeomLocal {
+    const v4 *nodes4; const v4 *tris4;
+    PT_MEM void node(uint32_t i, v4 &a, v4 &b) const { a = nodes4[2u * i]; b = nodes4[2u * i + 1u]; }
+    PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { a = tris4[3u * k]; b = tris4[3u * k + 1u]; c = tris4[3u * k + 2u]; }
+};
 
 // ANY = false: closest hit (intersect); ANY = true: any hit (intersect_p).
 // Stack must provide push(uint32_t), pop(), empty() and clear().
@@ -50,11 +57,11 @@ PT_HD void load_tri(const DTri *tris, uint32_t k, f3 &p0, f3 &p1, f3 &p2, uint32
 // 64-lane wave the (expensive) triangle phase runs with most lanes active instead of once per
 // interior step.  Per ray the sequence of nodes and triangles visited is exactly that of the
 // reference loop (accelerator.rs:372-414), only the interleaving between lanes differs.
-template <bool ANY, class Stack>
-PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
-    out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f;
+template <bool ANY, class Stack, class Geom>
+PT_HD bool bvh_trace_g(const Geom &G, uint32_t n_nodes_total, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+    out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f; out.flags = 0;
     stack.clear(); // an any-hit query may have returned early and left entries behind
-    if (sc.n_nodes == 0) return false;
+    if (n_nodes_total == 0) return false;
     f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
     const uint32_t NONE = 0xffffffffu;
@@ -64,8 +71,8 @@ PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, Hi
         // phase 1: descend until a leaf is accepted
         uint32_t leaf_first = 0, leaf_count = 0;
         while (cur != NONE) {
-            const v4 *np = reinterpret_cast<const v4 *>(sc.nodes + cur);
-            const v4 a = np[0], b = np[1];
+            v4 a, b;
+            G.node(cur, a, b);
             ++n_nodes;
             if (slab_test(a, b, o, inv, neg, t_max)) {
                 const uint32_t offset = f2u(b.z), meta = f2u(b.w);
@@ -84,18 +91,26 @@ PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, Hi
         }
         // phase 2: the leaf's triangles, in order
         for (uint32_t i = 0; i < leaf_count; ++i) {
-            f3 p0, p1, p2; uint32_t prim, flags;
-            load_tri(sc.tris, leaf_first + i, p0, p1, p2, prim, flags);
+            v4 ta, tb, tc;
+            G.tri(leaf_first + i, ta, tb, tc);
+            const f3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
+            const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
             ++n_tris;
             TriHit h;
             if (tri_test(o, d, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
                 if (ANY) { out.prim = 0; return true; }
                 hit = true; t_max = h.t;
-                out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2;
+                out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
             }
         }
     }
     return hit;
+}
+
+template <bool ANY, class Stack>
+PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+    GeomGlobal G; G.nodes = sc.nodes; G.tris = sc.tris;
+    return bvh_trace_g<ANY>(G, sc.n_nodes, o, d, t_max, stack, out, n_nodes, n_tris);
 }
 
 struct LocalStack { // host twin / small fixed uses

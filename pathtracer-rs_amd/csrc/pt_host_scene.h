@@ -141,8 +141,15 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
     H.mats.resize(d.n_materials);
     for (uint32_t i = 0; i < d.n_materials; ++i) {
         const PtrsMaterial &s = d.materials[i]; DMaterial &m = H.mats[i];
+        std::memset(&m, 0, sizeof(m));
         m.kind = s.kind; m.flags = s.flags; m.inner = s.inner;
-        for (int k = 0; k < 6; ++k) m.tex[k] = s.tex[k];
+        for (int k = 0; k < 6; ++k) {
+            m.tex[k] = s.tex[k];
+            if (s.tex[k] >= 0 && (uint32_t)s.tex[k] < d.n_textures && d.textures[s.tex[k]].kind == PTRS_TEX_CONSTANT) { // fold ConstantTexture values
+                m.const_mask |= 1u << k;
+                for (int c = 0; c < 3; ++c) m.cval[k][c] = d.textures[s.tex[k]].value[c];
+            }
+        }
         bool ok = true;
         switch (s.kind) {
             case PTRS_MAT_MATTE: ok = tex_ok(s.tex[0], 3); break;
@@ -177,20 +184,28 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             std::memset(&T, 0, sizeof(T));
             uint32_t v[3] = {s.indices[3 * t], s.indices[3 * t + 1], s.indices[3 * t + 2]};
             for (int k = 0; k < 3; ++k) if (v[k] >= s.n_verts) return bad("vertex index out of range");
-            float *P[3] = {T.p0, T.p1, T.p2}, *N[3] = {T.n0, T.n1, T.n2}, *S[3] = {T.s0, T.s1, T.s2}, *UV[3] = {T.uv0, T.uv1, T.uv2};
-            const float duv[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}}; // shape.rs:41-46
-            for (int k = 0; k < 3; ++k) {
-                for (int c = 0; c < 3; ++c) {
-                    P[k][c] = s.pos[3 * v[k] + c];
-                    if (s.normal) N[k][c] = s.normal[3 * v[k] + c];
-                    if (s.tangent) S[k][c] = s.tangent[3 * v[k] + c];
-                }
-                for (int c = 0; c < 2; ++c) UV[k][c] = s.uv ? s.uv[2 * v[k] + c] : duv[k][c];
+            auto P3 = [&](const float *src, uint32_t vi, int c) { return src[3 * vi + c]; };
+            T.p0[0] = P3(s.pos, v[0], 0); T.p0[1] = P3(s.pos, v[0], 1); T.p0[2] = P3(s.pos, v[0], 2);
+            T.p1x = P3(s.pos, v[1], 0); T.p1y = P3(s.pos, v[1], 1); T.p1z = P3(s.pos, v[1], 2);
+            T.p2x = P3(s.pos, v[2], 0); T.p2y = P3(s.pos, v[2], 1); T.p2z = P3(s.pos, v[2], 2);
+            if (s.normal) {
+                T.n0[0] = P3(s.normal, v[0], 0); T.n0[1] = P3(s.normal, v[0], 1); T.n0[2] = P3(s.normal, v[0], 2);
+                T.n1x = P3(s.normal, v[1], 0); T.n1y = P3(s.normal, v[1], 1); T.n1z = P3(s.normal, v[1], 2);
+                T.n2x = P3(s.normal, v[2], 0); T.n2y = P3(s.normal, v[2], 1); T.n2z = P3(s.normal, v[2], 2);
             }
+            if (s.tangent) {
+                T.s0[0] = P3(s.tangent, v[0], 0); T.s0[1] = P3(s.tangent, v[0], 1); T.s0[2] = P3(s.tangent, v[0], 2);
+                T.s1x = P3(s.tangent, v[1], 0); T.s1y = P3(s.tangent, v[1], 1); T.s1z = P3(s.tangent, v[1], 2);
+                T.s2x = P3(s.tangent, v[2], 0); T.s2y = P3(s.tangent, v[2], 1); T.s2z = P3(s.tangent, v[2], 2);
+            }
+            const float duv[3][2] = {{0.0f, 0.0f}, {1.0f, 0.0f}, {1.0f, 1.0f}}; // shape.rs:41-46
+            float *UV[3] = {T.uv0, T.uv1, T.uv2};
+            for (int k = 0; k < 3; ++k) for (int c = 0; c < 2; ++c) UV[k][c] = s.uv ? s.uv[2 * v[k] + c] : duv[k][c];
             T.material = s.material; T.light = -1; T.alpha_tex = s.alpha_mask_tex;
-            T.flags = (s.normal ? TRI_HAS_NORMAL : 0u) | (s.tangent ? TRI_HAS_TANGENT : 0u) | (s.reverse_orientation ? TRI_REVERSE : 0u) | (s.transform_swaps_handedness ? TRI_SWAPS : 0u);
+            T.flags = (s.normal ? TRI_HAS_NORMAL : 0u) | (s.tangent ? TRI_HAS_TANGENT : 0u) | (s.reverse_orientation ? TRI_REVERSE : 0u) | (s.transform_swaps_handedness ? TRI_SWAPS : 0u) |
+                      ((uint32_t)bucket << TRI_BUCKET_SHIFT);
             f3 dpdu, dpdv;
-            if (!tri_dpduv(ld3(T.p0), ld3(T.p1), ld3(T.p2), mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), dpdu, dpdv)) T.flags |= TRI_DEGENERATE;
+            if (!tri_dpduv(mk3(T.p0[0], T.p0[1], T.p0[2]), mk3(T.p1x, T.p1y, T.p1z), mk3(T.p2x, T.p2y, T.p2z), mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), dpdu, dpdv)) T.flags |= TRI_DEGENERATE;
         }
     }
     // ---- lights ---------------------------------------------------------------------------------
@@ -205,8 +220,10 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             if (s.mesh >= d.n_meshes || s.tri >= d.meshes[s.mesh].n_tris || !tex_ok(s.ke_tex, 3)) return bad("bad area light record");
             L.tri = (int32_t)(mesh_first[s.mesh] + s.tri); L.ke_tex = s.ke_tex;
             DTriShade &T = H.shade[L.tri];
-            T.light = (int32_t)i;
-            L.area = 0.5f * len(cross(ld3(T.p1) - ld3(T.p0), ld3(T.p2) - ld3(T.p0))); // Triangle::area, shape.rs:533-539
+            T.light = (int32_t)i; T.flags |= TRI_IS_LIGHT;
+            const f3 q0 = mk3(T.p0[0], T.p0[1], T.p0[2]), q1 = mk3(T.p1x, T.p1y, T.p1z), q2 = mk3(T.p2x, T.p2y, T.p2z);
+            L.area = 0.5f * len(cross(q1 - q0, q2 - q0)); // Triangle::area, shape.rs:533-539
+            if (d.textures[s.ke_tex].kind == PTRS_TEX_CONSTANT) { L.ke_const = 1u; for (int c = 0; c < 3; ++c) L.c[c] = d.textures[s.ke_tex].value[c]; }
         } else if (s.kind == PTRS_LIGHT_INFINITE) {
             if (!tex_ok(s.lmap_tex, 3) || d.textures[s.lmap_tex].kind != PTRS_TEX_IMAGE || s.dist_nu <= 0 || s.dist_nv <= 0 || !s.dist_func || !s.dist_cdf || !s.dist_func_int || !s.marg_cdf) return bad("bad infinite light record");
             L.lmap_tex = s.lmap_tex;
@@ -220,6 +237,7 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             H.inf_lights.push_back(i);
         } else if (s.kind != PTRS_LIGHT_POINT && s.kind != PTRS_LIGHT_DIRECTIONAL) { err = "unknown light kind"; return PTRS_ERR_UNSUPPORTED; }
     }
+    for (auto &L : H.lights) if (L.kind == PTRS_LIGHT_AREA) L.T = H.shade[L.tri];
     // ---- accelerator ----------------------------------------------------------------------------
     std::vector<uint32_t> order;
     if (d.bvh_nodes && d.n_bvh_nodes) {
@@ -242,7 +260,8 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
         for (size_t i = 0; i < n_tris; ++i) {
             hostbvh::Item &it = B.items[i]; it.prim = (uint32_t)i; it.b = hostbvh::empty_box();
             const DTriShade &T = H.shade[i];
-            hostbvh::grow_pt(it.b, T.p0); hostbvh::grow_pt(it.b, T.p1); hostbvh::grow_pt(it.b, T.p2);
+            const float q1[3] = {T.p1x, T.p1y, T.p1z}, q2[3] = {T.p2x, T.p2y, T.p2z};
+            hostbvh::grow_pt(it.b, T.p0); hostbvh::grow_pt(it.b, q1); hostbvh::grow_pt(it.b, q2);
             for (int k = 0; k < 3; ++k) it.c[k] = it.b.lo[k] + 0.5f * (it.b.hi[k] - it.b.lo[k]);
         }
         H.nodes.reserve(2 * n_tris);
@@ -255,8 +274,8 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
     H.tris.resize(order.size());
     for (size_t k = 0; k < order.size(); ++k) {
         const DTriShade &T = H.shade[order[k]]; DTri &t = H.tris[k];
-        t.p0[0] = T.p0[0]; t.p0[1] = T.p0[1]; t.p0[2] = T.p0[2]; t.p1x = T.p1[0]; t.p1y = T.p1[1]; t.p1z = T.p1[2];
-        t.p2x = T.p2[0]; t.p2y = T.p2[1]; t.p2z = T.p2[2]; t.prim = order[k]; t.flags = T.flags; t.alpha_tex = T.alpha_tex;
+        t.p0[0] = T.p0[0]; t.p0[1] = T.p0[1]; t.p0[2] = T.p0[2]; t.p1x = T.p1x; t.p1y = T.p1y; t.p1z = T.p1z;
+        t.p2x = T.p2x; t.p2y = T.p2y; t.p2z = T.p2z; t.prim = order[k]; t.flags = T.flags; t.alpha_tex = T.alpha_tex;
     }
     return PTRS_OK;
 }

@@ -71,12 +71,6 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
 PT_HD int32_t st_bounces(uint32_t z) { return (int32_t)(int16_t)(z >> ST_BOUNCE_SHIFT); }
 PT_HD uint32_t st_pack(uint32_t dim, uint32_t flags, int32_t bounces) { return (dim & ST_DIM_MASK) | flags | ((uint32_t)(uint16_t)(int16_t)bounces << ST_BOUNCE_SHIFT); }
 
-// effective material kind for bucketing (NormalMaterial defers to the material it wraps)
-PT_HD int material_bucket(const DScene &sc, int32_t mat) {
-    DMaterial m = sc.mats[mat];
-    for (int g = 0; g < 4 && m.kind == 6; ++g) m = sc.mats[m.inner];
-    return m.kind;
-}
 
 // Epilogue of the extension trace (integrator.rs:418-431): emission at the first vertex / after a
 // specular bounce, environment radiance for escaped rays, the depth cut -- then the material bucket.
@@ -88,8 +82,8 @@ PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P
     const int32_t bounces = st_bounces(stz);
     if (bounces == 0 || (stz & ST_SPECULAR)) {
         if (prim >= 0) {
-            const DTriShade &T = sc.shade[prim];
-            if (T.light >= 0) {
+            if (h.flags & TRI_IS_LIGHT) {
+                const TriRegs T = load_tri_regs(sc.shade + prim);
                 f3 d = xyz(P.ray_d[pid]);
                 Surface s = tri_surface(T, prim, h.b0, h.b1, h.b2, -d);
                 f3 le = surface_le<FEAT>(sc, T, s, -d);
@@ -106,7 +100,7 @@ PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P
         }
     }
     if (prim < 0 || bounces >= R.max_depth) return -1;
-    return material_bucket(sc, sc.shade[prim].material);
+    return (int)((h.flags >> TRI_BUCKET_SHIFT) & 7u); // material bucket, carried by the leaf triangle record
 }
 
 struct ShadeResult { bool next; bool nee; bool shadow; bool mis; };
@@ -122,7 +116,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     u4 stv = P.st[pid];
     u4 h = P.hit[pid];
     const int32_t prim = (int32_t)h.x;
-    const DTriShade &T = sc.shade[prim];
+    const TriRegs T = load_tri_regs(sc.shade + prim);
     int32_t bounces = st_bounces(stv.z);
     PathCoord c = path_coord(R, S, pid);
     SamplerState ss;
@@ -238,8 +232,8 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 // The two scene queries of estimate_direct and its use of their results: shadow any-hit
 // (integrator.rs:66-78, light.rs:38-42), MIS closest hit (119-134), then `l += beta * nLights * ld`
 // (444-446, 206-216).  One NEE record per call.
-template <int FEAT, class Stack>
-PT_HD void connect_item(const DScene &sc, const DPaths &P, uint32_t pid, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
+template <int FEAT, class Stack, class Geom>
+PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t pid, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
     const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
     const u4 n2 = P.nee2[pid];
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
@@ -247,7 +241,7 @@ PT_HD void connect_item(const DScene &sc, const DPaths &P, uint32_t pid, Stack &
     if (fl & NEE_SHADOW) {
         const v4 o = P.sh_o[pid], d = P.sh_d[pid];
         HitRec h;
-        if (!bvh_trace<true>(sc, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris)) ld = ld + xyz(n0);
+        if (!bvh_trace_g<true>(G, sc.n_nodes, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris)) ld = ld + xyz(n0);
     }
     if (fl & NEE_MIS) {
         const DLight &Lt = sc.lights[li];
@@ -255,8 +249,8 @@ PT_HD void connect_item(const DScene &sc, const DPaths &P, uint32_t pid, Stack &
         const f3 wi = xyz(P.mis_d[pid]);
         HitRec h;
         f3 l2 = splat3(0.0f);
-        if (bvh_trace<false>(sc, xyz(o), wi, PT_INF, stack, h, n_nodes, n_tris)) {
-            const DTriShade &T = sc.shade[h.prim];
+        if (bvh_trace_g<false>(G, sc.n_nodes, xyz(o), wi, PT_INF, stack, h, n_nodes, n_tris)) {
+            const TriRegs T = load_tri_regs(sc.shade + h.prim);
             if (T.light == (int32_t)li) { // std::ptr::eq(light, isect_light) (Q11)
                 Surface s = tri_surface(T, h.prim, h.b0, h.b1, h.b2, -wi);
                 l2 = surface_le<FEAT>(sc, T, s, -wi);

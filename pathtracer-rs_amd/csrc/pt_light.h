@@ -16,41 +16,41 @@ struct LightSample {
 };
 
 // Triangle::sample (shape.rs:541-578): point, face-forwarded normal, error bound, uv
-PT_HD void tri_sample(const DTriShade &T, f2 u, f3 &p, f3 &n, f3 &perr, f2 &uv) {
+PT_HD void tri_sample(const TriRegs &T, f2 u, f3 &p, f3 &n, f3 &perr, f2 &uv) {
     float su0 = sqrt_(u.x);
     float b0 = 1.0f - su0, b1 = u.y * su0;
-    f3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
+    f3 p0 = T.p0, p1 = T.p1, p2 = T.p2;
     float b2 = 1.0f - b0 - b1;
     p = (b0 * p0) + (b1 * p1) + b2 * p2;
     n = normalize(cross(p1 - p0, p2 - p0));
     if (T.flags & TRI_HAS_NORMAL) {
-        f3 ns = (b0 * ld3(T.n0)) + (b1 * ld3(T.n1)) + b2 * ld3(T.n2);
+        f3 ns = (b0 * T.n0) + (b1 * T.n1) + b2 * T.n2;
         n = face_forward(n, ns);
     } else if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) n = n * -1.0f;
     perr = gamma_err(6) * (abs3(b0 * p0) + abs3(b1 * p1) + abs3(b2 * p2));
-    uv = mk2(b0 * T.uv0[0] + b1 * T.uv1[0] + b2 * T.uv2[0], b0 * T.uv0[1] + b1 * T.uv1[1] + b2 * T.uv2[1]);
+    uv = mk2(b0 * T.uv0.x + b1 * T.uv1.x + b2 * T.uv2.x, b0 * T.uv0.y + b1 * T.uv1.y + b2 * T.uv2.y);
 }
 
 // the two hit-record fields pdf_at_point needs: p (shape.rs:224) and general.n after
 // set_shading_geometry's face-forwarding (shape.rs:261-356, interaction.rs:200-204) -- same
 // arithmetic as tri_surface, minus everything that does not feed them
-PT_HD void tri_point_normal(const DTriShade &T, float b0, float b1, float b2, f3 &p, f3 &n) {
-    f3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
+PT_HD void tri_point_normal(const TriRegs &T, float b0, float b1, float b2, f3 &p, f3 &n) {
+    f3 p0 = T.p0, p1 = T.p1, p2 = T.p2;
     p = b0 * p0 + b1 * p1 + b2 * p2;
     n = normalize(cross(p0 - p2, p1 - p2));
     if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) n = -n;
     if (T.flags & (TRI_HAS_NORMAL | TRI_HAS_TANGENT)) {
         f3 ns;
         if (T.flags & TRI_HAS_NORMAL) {
-            ns = b0 * ld3(T.n0) + b1 * ld3(T.n1) + b2 * ld3(T.n2);
+            ns = b0 * T.n0 + b1 * T.n1 + b2 * T.n2;
             ns = len2(ns) > 0.0f ? normalize(ns) : n;
         } else ns = n;
         f3 ss;
         if (T.flags & TRI_HAS_TANGENT) {
-            ss = b0 * ld3(T.s0) + b1 * ld3(T.s1) + b2 * ld3(T.s2);
+            ss = b0 * T.s0 + b1 * T.s1 + b2 * T.s2;
             if (len2(ss) > 0.0f) ss = normalize(ss);
-            else { f3 du, dv; tri_dpduv(p0, p1, p2, mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), du, dv); ss = normalize(du); }
-        } else { f3 du, dv; tri_dpduv(p0, p1, p2, mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), du, dv); ss = normalize(du); }
+            else { f3 du, dv; tri_dpduv(p0, p1, p2, T.uv0, T.uv1, T.uv2, du, dv); ss = normalize(du); }
+        } else { f3 du, dv; tri_dpduv(p0, p1, p2, T.uv0, T.uv1, T.uv2, du, dv); ss = normalize(du); }
         f3 ts = cross(ss, ns);
         if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
         else coordinate_system(ns, ss, ts);
@@ -60,10 +60,10 @@ PT_HD void tri_point_normal(const DTriShade &T, float b0, float b1, float b2, f3
 }
 
 // Triangle::pdf_at_point (shape.rs:62-72): a single-triangle intersection from the offset origin
-PT_HD float tri_pdf_at_point(const DTriShade &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi) {
+PT_HD float tri_pdf_at_point(const TriRegs &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi) {
     f3 o = spawn_origin(ref_p, ref_err, ref_n, wi);
     TriHit h;
-    if (!tri_test(o, wi, PT_INF, ld3(T.p0), ld3(T.p1), ld3(T.p2), h)) return 0.0f;
+    if (!tri_test(o, wi, PT_INF, T.p0, T.p1, T.p2, h)) return 0.0f;
     if (T.flags & TRI_DEGENERATE) return 0.0f;
     f3 p, n;
     tri_point_normal(T, h.b0, h.b1, h.b2, p, n);
@@ -100,15 +100,15 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
         o.li = ld3(L.c);
         return true;
     }
-    if (L.kind == 2) { // diffuse area light on one triangle
-        const DTriShade &T = sc.shade[L.tri];
+    if (L.kind == 2) { // diffuse area light on one triangle (its record is embedded in the light)
+        const TriRegs T = load_tri_regs(&L.T);
         f3 p, n, perr; f2 uv;
         tri_sample(T, u, p, n, perr, uv);
         o.wi = normalize(p - ref_p);
         o.pdf = tri_pdf_at_point(T, L.area, ref_p, ref_err, ref_n, o.wi);
         o.p1 = p; o.p1_err = perr; o.p1_n = n;
         f3 w = -o.wi;
-        o.li = dot(n, w) > 0.0f ? tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f) : splat3(0.0f);
+        o.li = dot(n, w) > 0.0f ? (L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f)) : splat3(0.0f);
         return true;
     }
     if (!(FEAT & FEAT_INFINITE)) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; } // unreachable
@@ -130,7 +130,7 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
 
 template <int FEAT>
 PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f3 w) {
-    if (L.kind == 2) return tri_pdf_at_point(sc.shade[L.tri], L.area, ref_p, ref_err, ref_n, w);
+    if (L.kind == 2) return tri_pdf_at_point(load_tri_regs(&L.T), L.area, ref_p, ref_err, ref_n, w);
     if ((FEAT & FEAT_INFINITE) && L.kind == 3) {
         f3 wi = xform_vec(L.w2l, w);
         float theta = spherical_theta(wi), phi = spherical_phi(wi);
@@ -160,9 +160,12 @@ PT_HD f3 light_le(const DScene &sc, const DLight &L, f3 d) {
 
 // SurfaceMediumInteraction::le (interaction.rs:297-303) + DiffuseAreaLight::l (light.rs:252-258)
 template <int FEAT>
-PT_HD f3 surface_le(const DScene &sc, const DTriShade &T, const Surface &s, f3 w) {
+PT_HD f3 surface_le(const DScene &sc, const TriRegs &T, const Surface &s, f3 w) {
     if (T.light < 0) return splat3(0.0f);
-    if (dot(s.n, w) > 0.0f) return tex_eval<FEAT>(sc, sc.lights[T.light].ke_tex, s);
+    if (dot(s.n, w) > 0.0f) {
+        const DLight &L = sc.lights[T.light];
+        return L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, s);
+    }
     return splat3(0.0f);
 }
 

@@ -31,6 +31,13 @@ PT_HD void normal_mapping(const DScene &sc, int32_t tex, Surface &s) { // mod.rs
     s.ns = ns; s.s_dpdu = ss; s.s_dpdv = ts;
 }
 
+// texture slot k of material m: the folded constant when the texture is a ConstantTexture
+template <int FEAT>
+PT_HD f3 mat_tex(const DScene &sc, const DMaterial &m, int k, const Surface &s) {
+    if (m.const_mask & (1u << k)) return mk3(m.cval[k][0], m.cval[k][1], m.cval[k][2]);
+    return tex_eval<FEAT>(sc, m.tex[k], s);
+}
+
 // number of lobe slots per material kind (Disney: DisneyDiffuse + MicrofacetReflection)
 template <int MAT> struct MatLobes { static constexpr int N = (MAT == 4) ? 2 : 1; };
 
@@ -38,16 +45,17 @@ template <int MAT> struct MatLobes { static constexpr int N = (MAT == 4) ? 2 : 1
 // Returns false when the material yields no BSDF (glass with black r and t, Q17).
 template <int MAT, int FEAT>
 PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, BsdfT<MatLobes<MAT>::N> &b) {
-    DMaterial m = sc.mats[mat_id];
+    const DMaterial *mp = sc.mats + mat_id;
     if (FEAT & FEAT_NORMAL) { // NormalMaterial wraps another material (mod.rs:136-141)
-        for (int guard = 0; guard < 4 && m.kind == 6; ++guard) {
-            normal_mapping<FEAT>(sc, m.tex[0], s);
-            m = sc.mats[m.inner];
+        for (int guard = 0; guard < 4 && mp->kind == 6; ++guard) {
+            normal_mapping<FEAT>(sc, mp->tex[0], s);
+            mp = sc.mats + mp->inner;
         }
     }
+    const DMaterial &m = *mp;
     if (MAT == 0) { // Matte, mod.rs:155-167
         bsdf_init(b, s, 1.0f);
-        Lobe l = blank_lobe(LOBE_LAMBERT); l.r = tex_eval<FEAT>(sc, m.tex[0], s);
+        Lobe l = blank_lobe(LOBE_LAMBERT); l.r = mat_tex<FEAT>(sc, m, 0, s);
         b.lobe[0] = l; b.n = 1;
         return true;
     } else if (MAT == 2) { // Mirror, mod.rs:180-195
@@ -56,8 +64,8 @@ PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, BsdfT<MatLobe
         b.lobe[0] = l; b.n = 1;
         return true;
     } else if (MAT == 3) { // Glass, mod.rs:216-255
-        float eta = tex_eval<FEAT>(sc, m.tex[2], s).x;
-        f3 r = tex_eval<FEAT>(sc, m.tex[0], s), t = tex_eval<FEAT>(sc, m.tex[1], s);
+        float eta = mat_tex<FEAT>(sc, m, 2, s).x;
+        f3 r = mat_tex<FEAT>(sc, m, 0, s), t = mat_tex<FEAT>(sc, m, 1, s);
         bsdf_init(b, s, eta);
         if (is_black(r) && is_black(t)) return false;
         Lobe l = blank_lobe(LOBE_FRESNEL_SPEC); l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta;
@@ -65,18 +73,18 @@ PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, BsdfT<MatLobe
         return true;
     } else if (MAT == 1) { // Metal, metal.rs:49-94
         bsdf_init(b, s, 1.0f);
-        float ur = m.tex[4] >= 0 ? tex_eval<FEAT>(sc, m.tex[4], s).x : tex_eval<FEAT>(sc, m.tex[3], s).x;
-        float vr = m.tex[5] >= 0 ? tex_eval<FEAT>(sc, m.tex[5], s).x : tex_eval<FEAT>(sc, m.tex[3], s).x;
+        float ur = m.tex[4] >= 0 ? mat_tex<FEAT>(sc, m, 4, s).x : mat_tex<FEAT>(sc, m, 3, s).x;
+        float vr = m.tex[5] >= 0 ? mat_tex<FEAT>(sc, m, 5, s).x : mat_tex<FEAT>(sc, m, 3, s).x;
         if (m.flags & 1) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
-        Lobe l = blank_lobe(LOBE_MICRO_REFL); l.r = tex_eval<FEAT>(sc, m.tex[2], s);
+        Lobe l = blank_lobe(LOBE_MICRO_REFL); l.r = mat_tex<FEAT>(sc, m, 2, s);
         set_tr(l, ur, vr, false);
-        l.fresnel = FR_CONDUCTOR; l.fa = tex_eval<FEAT>(sc, m.tex[0], s); l.fb = tex_eval<FEAT>(sc, m.tex[1], s);
+        l.fresnel = FR_CONDUCTOR; l.fa = mat_tex<FEAT>(sc, m, 0, s); l.fb = mat_tex<FEAT>(sc, m, 1, s);
         b.lobe[0] = l; b.n = 1;
         return true;
     } else if (MAT == 5) { // Substrate, substrate.rs:42-68
         bsdf_init(b, s, 1.0f);
-        f3 d = tex_eval<FEAT>(sc, m.tex[0], s), sp = tex_eval<FEAT>(sc, m.tex[1], s);
-        float ru = tex_eval<FEAT>(sc, m.tex[2], s).x, rv = tex_eval<FEAT>(sc, m.tex[3], s).x;
+        f3 d = mat_tex<FEAT>(sc, m, 0, s), sp = mat_tex<FEAT>(sc, m, 1, s);
+        float ru = mat_tex<FEAT>(sc, m, 2, s).x, rv = mat_tex<FEAT>(sc, m, 3, s).x;
         Lobe l = blank_lobe(LOBE_FRESNEL_BLEND);
         if (!is_black(d) || is_black(sp)) { // Q20
             if (m.flags & 1) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
@@ -87,11 +95,11 @@ PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, BsdfT<MatLobe
         return true;
     } else { // Disney, disney.rs:172-264.  Slot 0 = DisneyDiffuse (only when diffuse_weight > 0), then MicrofacetReflection.
         bsdf_init(b, s, 1.0f);
-        f3 c = tex_eval<FEAT>(sc, m.tex[0], s);
-        float metallic = tex_eval<FEAT>(sc, m.tex[1], s).x, e = tex_eval<FEAT>(sc, m.tex[2], s).x;
+        f3 c = mat_tex<FEAT>(sc, m, 0, s);
+        float metallic = mat_tex<FEAT>(sc, m, 1, s).x, e = mat_tex<FEAT>(sc, m, 2, s).x;
         float strans = 0.0f;
         float diffuse_weight = (1.0f - metallic) * (1.0f - strans);
-        float rough = tex_eval<FEAT>(sc, m.tex[3], s).x;
+        float rough = mat_tex<FEAT>(sc, m, 3, s).x;
         float lum = luminance(c);
         f3 c_tint = lum > 0.0f ? c / lum : splat3(1.0f);
         float aspect = 1.0f;

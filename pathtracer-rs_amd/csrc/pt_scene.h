@@ -18,30 +18,42 @@ struct alignas(16) DNode { // = PtrsBvhNode = LinearBVHNode (accelerator.rs:89-9
     uint32_t meta;      // num_prims (low 16 bits) | axis << 16
 };
 
-enum : uint32_t { TRI_HAS_NORMAL = 1, TRI_HAS_TANGENT = 2, TRI_REVERSE = 8, TRI_SWAPS = 16, TRI_DEGENERATE = 32, TRI_HAS_ALPHA = 64 };
+enum : uint32_t { TRI_HAS_NORMAL = 1, TRI_HAS_TANGENT = 2, TRI_REVERSE = 8, TRI_SWAPS = 16, TRI_DEGENERATE = 32, TRI_HAS_ALPHA = 64,
+                  TRI_IS_LIGHT = 128,        // the triangle carries a DiffuseAreaLight
+                  TRI_BUCKET_SHIFT = 8 };    // bits 8..10: material bucket (kind of the innermost material)
 
-struct alignas(16) DTri { // leaf order
+struct alignas(16) DTri { // leaf order; read by traversal as 3 x 16 B
     float p0[3]; float p1x;
     float p1y, p1z; float p2x, p2y;
     float p2z; uint32_t prim; uint32_t flags; int32_t alpha_tex;
 };
 
-struct alignas(16) DTriShade { // indexed by global triangle id (mesh-major)
-    float p0[3], p1[3], p2[3];
-    float n0[3], n1[3], n2[3];
-    float uv0[2], uv1[2], uv2[2];
-    float s0[3], s1[3], s2[3];
-    int32_t material;
-    int32_t light; // index into lights[] or -1 (GeometricPrimitive::area_light)
-    uint32_t flags;
-    int32_t alpha_tex;
-    uint32_t pad[3];
+// Per-triangle shading record, indexed by global triangle id (mesh-major).  Ten 16-byte vectors so
+// the shade stage fetches it with wide loads (v0-v2 always, v3-v6 for normals/uvs, v7-v9 only when
+// the mesh has tangents).
+struct alignas(16) DTriShade {
+    float p0[3]; float p1x;                                   // v0
+    float p1y, p1z, p2x, p2y;                                 // v1
+    float p2z; int32_t material; int32_t light; uint32_t flags; // v2  light = index into lights[] or -1
+    float n0[3]; float n1x;                                   // v3
+    float n1y, n1z, n2x, n2y;                                 // v4
+    float n2z; int32_t alpha_tex; float uv0[2];               // v5
+    float uv1[2], uv2[2];                                     // v6
+    float s0[3]; float s1x;                                   // v7
+    float s1y, s1z, s2x, s2y;                                 // v8
+    float s2z; uint32_t pad[3];                               // v9
 };
 static_assert(sizeof(DNode) == 32, "node");
 static_assert(sizeof(DTri) == 48, "tri");
 static_assert(sizeof(DTriShade) == 160, "trishade");
 
-struct DMaterial { int32_t kind; int32_t tex[6]; int32_t flags; int32_t inner; };
+// tex[k] >= 0: texture id.  When that texture is a ConstantTexture its value is also folded into
+// cval[k] and bit k of const_mask is set, which saves the dependent texture-record fetch.
+struct alignas(16) DMaterial {
+    int32_t kind; int32_t flags; int32_t inner; uint32_t const_mask; // v0
+    int32_t tex[6]; int32_t pad[2];                                  // v1, v2(half)
+    float cval[6][4];                                                // rgb (or value in .x) per slot
+};
 struct DTexLevel { uint64_t offset; int32_t cols, rows; };
 struct DTexture {
     int32_t kind, channels;
@@ -50,16 +62,14 @@ struct DTexture {
     int32_t wrap, n_levels;
     uint32_t first_level; uint32_t pad;
 };
-struct DLight {
-    int32_t kind;
-    float v[3], c[3];
-    int32_t tri, ke_tex;
-    float area, world_radius;
-    int32_t lmap_tex;
-    float l2w[12], w2l[12];
-    int32_t nu, nv;
+struct alignas(16) DLight {
+    int32_t kind; int32_t tri; int32_t ke_tex; float area;      // v0
+    float v[3]; float world_radius;                             // v1
+    float c[3]; uint32_t ke_const;                              // v2  c = I / L, or the emission when ke is constant (ke_const = 1)
+    DTriShade T;                                                // area lights: a copy of the light's triangle record
+    int32_t lmap_tex; int32_t nu, nv; float marg_int;
     uint32_t func_off, cdf_off, fint_off, mcdf_off;
-    float marg_int;
+    float l2w[12], w2l[12];
 };
 
 struct DScene {
@@ -152,5 +162,27 @@ PT_HD float u2f(uint32_t u) { return ptf_from_bits(u); }
 PT_HD v4 mkv4(f3 a, float w) { v4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = w; return r; }
 PT_HD f3 xyz(v4 a) { return mk3(a.x, a.y, a.z); }
 PT_HD f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+
+// register copy of a DTriShade, filled by wide loads
+struct TriRegs {
+    f3 p0, p1, p2, n0, n1, n2, s0, s1, s2;
+    f2 uv0, uv1, uv2;
+    int32_t material, light, alpha_tex; uint32_t flags;
+};
+PT_HD TriRegs load_tri_regs(const DTriShade *rec) {
+    const v4 *q = reinterpret_cast<const v4 *>(rec);
+    TriRegs t;
+    const v4 a = q[0], b = q[1], c = q[2];
+    t.p0 = mk3(a.x, a.y, a.z); t.p1 = mk3(a.w, b.x, b.y); t.p2 = mk3(b.z, b.w, c.x);
+    t.material = (int32_t)f2u(c.y); t.light = (int32_t)f2u(c.z); t.flags = f2u(c.w);
+    const v4 d = q[3], e = q[4], f = q[5], g = q[6];
+    t.n0 = mk3(d.x, d.y, d.z); t.n1 = mk3(d.w, e.x, e.y); t.n2 = mk3(e.z, e.w, f.x);
+    t.alpha_tex = (int32_t)f2u(f.y); t.uv0 = mk2(f.z, f.w); t.uv1 = mk2(g.x, g.y); t.uv2 = mk2(g.z, g.w);
+    if (t.flags & TRI_HAS_TANGENT) {
+        const v4 h = q[7], i = q[8], j = q[9];
+        t.s0 = mk3(h.x, h.y, h.z); t.s1 = mk3(h.w, i.x, i.y); t.s2 = mk3(i.z, i.w, j.x);
+    } else { t.s0 = t.s1 = t.s2 = mk3(0.0f, 0.0f, 0.0f); }
+    return t;
+}
 
 } // namespace pt

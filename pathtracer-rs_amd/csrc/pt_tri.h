@@ -95,10 +95,10 @@ struct Surface {
 };
 
 // shape.rs:217-356 + interaction.rs:128-175,193-214 (SurfaceMediumInteraction::new, set_shading_geometry)
-PT_HD Surface tri_surface(const DTriShade &T, int32_t prim, float b0, float b1, float b2, f3 wo) {
+PT_HD Surface tri_surface(const TriRegs &T, int32_t prim, float b0, float b1, float b2, f3 wo) {
     Surface s;
-    f3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
-    f2 uv0 = mk2(T.uv0[0], T.uv0[1]), uv1 = mk2(T.uv1[0], T.uv1[1]), uv2 = mk2(T.uv2[0], T.uv2[1]);
+    f3 p0 = T.p0, p1 = T.p1, p2 = T.p2;
+    f2 uv0 = T.uv0, uv1 = T.uv1, uv2 = T.uv2;
     tri_dpduv(p0, p1, p2, uv0, uv1, uv2, s.dpdu, s.dpdv);
     float xs = fabs_(b0 * p0.x) + fabs_(b1 * p1.x) + fabs_(b2 * p2.x);
     float ys = fabs_(b0 * p0.y) + fabs_(b1 * p1.y) + fabs_(b2 * p2.y);
@@ -117,12 +117,12 @@ PT_HD Surface tri_surface(const DTriShade &T, int32_t prim, float b0, float b1, 
     if (T.flags & (TRI_HAS_NORMAL | TRI_HAS_TANGENT)) {
         f3 ns;
         if (T.flags & TRI_HAS_NORMAL) {
-            ns = b0 * ld3(T.n0) + b1 * ld3(T.n1) + b2 * ld3(T.n2);
+            ns = b0 * T.n0 + b1 * T.n1 + b2 * T.n2;
             ns = len2(ns) > 0.0f ? normalize(ns) : s.n;
         } else ns = s.n;
         f3 ss;
         if (T.flags & TRI_HAS_TANGENT) {
-            ss = b0 * ld3(T.s0) + b1 * ld3(T.s1) + b2 * ld3(T.s2);
+            ss = b0 * T.s0 + b1 * T.s1 + b2 * T.s2;
             ss = len2(ss) > 0.0f ? normalize(ss) : normalize(s.dpdu);
         } else ss = normalize(s.dpdu);
         f3 ts = cross(ss, ns);

@@ -51,6 +51,29 @@ __device__ inline uint32_t wave_push(uint32_t *counter, bool pred) {
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Segmented queues.  Every queue is split into G segments (G = grid size of the pass); workgroup b
+// appends only to segment b and, in the next kernel, workgroup b consumes segment b.  Slots are
+// handed out from an LDS counter (one ds_add per wave), the segment length is written once at the
+// end of the kernel: no global atomics at all.  (The first version used one global counter per
+// queue: ~16 M returning atomics per frame on a single address, which serialises at ~90/us and
+// was the bottleneck of every stage.)
+__device__ inline uint32_t block_push(uint32_t *lds_counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0xffffffffu;
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(lds_counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ inline void block_count(uint32_t *lds_counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m != 0ull && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(lds_counter, (uint32_t)__popcll(m));
+}
+// counts[(row * Q_STRIDE + q) * G + b]
+__device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uint32_t G, uint32_t b) { return Q.counts + ((size_t)row * Q_STRIDE + (size_t)q) * G + b; }
+
 struct LdsStack { // column `threadIdx.x` of a [depth][BLOCK] LDS array
     uint32_t *col;
     int n;
@@ -61,13 +84,22 @@ struct LdsStack { // column `threadIdx.x` of a [depth][BLOCK] LDS array
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCamera C, DPaths P, uint32_t *ext0, uint32_t *count0) {
-    const uint32_t stride = gridDim.x * BLOCK;
-    for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < R.n_paths; pid += stride) {
-        generate_item(R, S, C, P, pid);
-        ext0[pid] = pid;
+// Workgroup b generates the paths of its own segment: chunks of 256 consecutive path slots are dealt
+// round-robin to the G segments (coalesced state access per wave, even load across workgroups).
+__global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCamera C, DPaths P, DQueues Q, uint32_t seg_cap) {
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t chunks = (R.n_paths + BLOCK - 1) / BLOCK;
+    uint32_t *seg = Q.ext[0] + (size_t)b * seg_cap;
+    uint32_t n = 0;
+    for (uint32_t c = b; c < chunks; c += G) {
+        const uint32_t pid = c * BLOCK + threadIdx.x;
+        if (pid < R.n_paths) {
+            generate_item(R, S, C, P, pid);
+            seg[(c / G) * BLOCK + threadIdx.x] = pid;
+        }
+        n += (c * BLOCK + BLOCK <= R.n_paths) ? BLOCK : (R.n_paths - c * BLOCK);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count0 = R.n_paths;
+    if (threadIdx.x == 0) *seg_count(Q, 0, Q_EXT, G, b) = n;
 }
 
 // Ray source: (ro, rd) indexed by path slot, ro.w = t_max.  ANY: write occl[pid]; else write hits[pid].
@@ -94,29 +126,49 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const uint32_t *__re
 // Extension rays: closest-hit traversal, then the epilogue of integrator.rs:418-431 and the
 // wavefront-ballot bucketing of surviving paths by material kind (one ballot + one atomic per wave
 // and bucket).
-template <int FEAT, int DEPTH>
-__global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask) {
+// Stage the scene's nodes and leaf-ordered triangles into LDS as 16-byte vectors (GEOM = capacity in
+// vectors; host guarantees 2*n_nodes + 3*n_prims <= GEOM).
+template <int GEOM>
+__device__ inline GeomLocal stage_geometry(const DScene &sc, v4 *lds) {
+    const uint32_t nn4 = 2u * sc.n_nodes, nt4 = 3u * sc.n_prims;
+    const v4 *gn = reinterpret_cast<const v4 *>(sc.nodes), *gt = reinterpret_cast<const v4 *>(sc.tris);
+    for (uint32_t i = threadIdx.x; i < nn4; i += BLOCK) lds[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < nt4; i += BLOCK) lds[nn4 + i] = gt[i];
+    __syncthreads();
+    GeomLocal G; G.nodes4 = lds; G.tris4 = lds + nn4;
+    return G;
+}
+
+template <int FEAT, int DEPTH, int GEOM>
+__global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
-    const uint32_t *__restrict__ queue = Q.ext[it & 1u];
-    uint32_t *counts = Q.counts + (size_t)it * Q_STRIDE;
-    const uint32_t n = counts[Q_EXT];
-    const uint32_t stride = gridDim.x * BLOCK;
+    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
+    __shared__ uint32_t lcount[8];
+    GeomLocal GL; GeomGlobal GG; GG.nodes = sc.nodes; GG.tris = sc.tris;
+    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
+    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_EXT, G, b);
     uint32_t nn = 0, nt = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
         const uint32_t pid = queue[i];
         const v4 o = P.ray_o[pid], d = P.ray_d[pid];
         LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
         HitRec h;
-        bvh_trace<false>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+        if (GEOM > 0) bvh_trace_g<false>(GL, sc.n_nodes, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+        else bvh_trace_g<false>(GG, sc.n_nodes, xyz(o), xyz(d), o.w, stk, h, nn, nt);
         u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
         P.hit[pid] = r;
         const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
-        for (int m = 0; m < 6; ++m) {
+        for (int m = 0; m < 6; ++m) { // wavefront-ballot bucketing by material kind
             if (!(kinds_mask & (1u << m))) continue;
-            const uint32_t slot = wave_push(&counts[Q_MAT0 + m], k == m);
-            if (k == m) Q.mat[m][slot] = pid;
+            const uint32_t slot = block_push(&lcount[m], k == m);
+            if (k == m) Q.mat[m][(size_t)b * seg_cap + slot] = pid;
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 6 && (kinds_mask & (1u << threadIdx.x))) *seg_count(Q, it, Q_MAT0 + (int)threadIdx.x, G, b) = lcount[threadIdx.x];
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
 
@@ -126,38 +178,70 @@ __device__ inline void wave_count(uint32_t *counter, bool pred) {
 }
 
 // One instantiation per material kind (and feature set): lobe kinds are compile-time constants.
+#ifndef PTRS_SHADE_WAVES
+#define PTRS_SHADE_WAVES 1
+#endif
 template <int MAT, int FEAT>
-__global__ __launch_bounds__(BLOCK) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it) {
-    const uint32_t *__restrict__ queue = Q.mat[MAT];
-    uint32_t *counts = Q.counts + (size_t)it * Q_STRIDE;
-    uint32_t *next_count = Q.counts + (size_t)(it + 1u) * Q_STRIDE + Q_EXT;
-    uint32_t *next = Q.ext[(it + 1u) & 1u];
-    const uint32_t n = counts[Q_MAT0 + MAT];
-    const uint32_t stride = gridDim.x * BLOCK;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+__global__ __launch_bounds__(BLOCK, PTRS_SHADE_WAVES) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
+    __shared__ uint32_t lcount[4]; // next, nee, shadow rays, mis rays
+    if (threadIdx.x < 4) lcount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)b * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_MAT0 + MAT, G, b);
+    // several material kernels append to the same output segments one after the other
+    const uint32_t next_base = *seg_count(Q, it + 1u, Q_EXT, G, b), nee_base = *seg_count(Q, it, Q_NEE, G, b);
+    uint32_t *next = Q.ext[(it + 1u) & 1u] + (size_t)b * seg_cap + next_base;
+    uint32_t *nee = Q.nee + (size_t)b * seg_cap + nee_base;
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
         const uint32_t pid = queue[i];
         const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid);
-        uint32_t slot = wave_push(next_count, r.next);
+        uint32_t slot = block_push(&lcount[0], r.next);
         if (r.next) next[slot] = pid;
-        slot = wave_push(&counts[Q_NEE], r.nee);
-        if (r.nee) Q.nee[slot] = pid;
-        wave_count(&counts[Q_SHADOW], r.shadow);
-        wave_count(&counts[Q_MIS], r.mis);
+        slot = block_push(&lcount[1], r.nee);
+        if (r.nee) nee[slot] = pid;
+        block_count(&lcount[2], r.shadow);
+        block_count(&lcount[3], r.mis);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *seg_count(Q, it + 1u, Q_EXT, G, b) = next_base + lcount[0];
+        *seg_count(Q, it, Q_NEE, G, b) = nee_base + lcount[1];
+        *seg_count(Q, it, Q_SHADOW, G, b) += lcount[2];
+        *seg_count(Q, it, Q_MIS, G, b) += lcount[3];
     }
 }
 
 // Shadow (any-hit) and MIS (closest-hit) queries of the pending NEE records, resolved into L.
-template <int FEAT, int DEPTH>
-__global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it) {
+template <int FEAT, int DEPTH, int GEOM>
+__global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
-    const uint32_t n = Q.counts[(size_t)it * Q_STRIDE + Q_NEE];
-    const uint32_t stride = gridDim.x * BLOCK;
+    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
+    GeomLocal GL; GeomGlobal GG; GG.nodes = sc.nodes; GG.tris = sc.tris;
+    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom);
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
     uint32_t nn = 0, nt = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
         LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
-        connect_item<FEAT>(sc, P, Q.nee[i], stk, nn, nt);
+        if (GEOM > 0) connect_item<FEAT>(sc, GL, P, queue[i], stk, nn, nt);
+        else connect_item<FEAT>(sc, GG, P, queue[i], stk, nn, nt);
     }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
+}
+
+// totals[row*Q_STRIDE + q] = sum over segments of counts[(row*Q_STRIDE + q)*G + b]; one workgroup per (row, q)
+__global__ __launch_bounds__(BLOCK) void k_reduce_counts(const uint32_t *__restrict__ counts, uint32_t G, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    uint32_t v = 0;
+    for (uint32_t b = threadIdx.x; b < G; b += BLOCK) v += counts[(size_t)blockIdx.x * G + b];
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_down((int)v, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&acc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) totals[blockIdx.x] = acc;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P, const float *__restrict__ table, v4 *film, int32_t y0, int32_t y1) {
@@ -254,11 +338,11 @@ struct PtrsScene {
     DevBuf nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
     // render workspace, grown on demand and reused across calls
     DevBuf ws[32];
-    DevBuf counts, stats, table, film_tmp, samples_tmp;
+    DevBuf counts, totals, stats, table, film_tmp, samples_tmp;
     std::vector<hipEvent_t> ev_pool;
     int n_cu = 256;
     ~PtrsScene() {
-        for (auto &b : {&nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &stats, &table, &film_tmp, &samples_tmp}) b->release();
+        for (auto &b : {&nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
         for (auto &b : ws) b.release();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
@@ -271,6 +355,8 @@ struct HipBackend {
     DScene sc; DSampler S; DCamera C; DParams R; DPaths P; DQueues Q;
     uint32_t cap = 0, rows = 0, depth = 0, flags = 0, kinds_mask = 0;
     int feat = FEAT_FULL;
+    uint32_t geom4 = 0xffffffffu; // 16-byte vectors needed to hold nodes + triangles in LDS
+    uint32_t G = 1, seg_cap = 0;  // segmented queues of the current pass
     int grid_max = 2048;
     int rc = PTRS_OK;
     // timing
@@ -294,8 +380,9 @@ struct HipBackend {
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_;
         grid_max = ps->n_cu * 8;
+        geom4 = getenv("PTRS_NO_LDS_GEOM") ? 0xffffffffu : 2u * sc.n_nodes + 3u * sc.n_prims;
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
-        const size_t n16 = (size_t)cap * 16, n4 = (size_t)cap * 4;
+        const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
         void **slots16[] = {(void **)&P.ray_o, (void **)&P.ray_d, (void **)&P.beta, (void **)&P.L, (void **)&P.st, (void **)&P.hit, (void **)&P.pfilm, (void **)&P.nee0,
                             (void **)&P.nee1, (void **)&P.nee2, (void **)&P.sh_o, (void **)&P.sh_d, (void **)&P.mis_o, (void **)&P.mis_d};
         int w = 0;
@@ -307,44 +394,66 @@ struct HipBackend {
             if (kinds_mask & (1u << k)) { if ((rc = ps->ws[w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } Q.mat[k] = (uint32_t *)ps->ws[w].p; }
             ++w;
         }
-        if ((rc = ps->counts.ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK || (rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
+        if ((rc = ps->counts.ensure((size_t)rows * Q_STRIDE * (size_t)grid_max * 4)) != PTRS_OK || (rc = ps->totals.ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK || (rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
         Q.counts = (uint32_t *)ps->counts.p; Q.stats = (unsigned long long *)ps->stats.p;
         float tab[256]; gaussian_filter_table(tab);
         if (hipMemcpyAsync(ps->table.p, tab, 1024, hipMemcpyHostToDevice, stream) != hipSuccess || hipMemsetAsync(Q.stats, 0, CNT_NUM * 8, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { err = "workspace initialisation failed"; return PTRS_ERR_DEVICE; }
         return PTRS_OK;
     }
-    void pass_begin(const DParams &R_) { R = R_; (void)hipMemsetAsync(Q.counts, 0, (size_t)rows * Q_STRIDE * 4, stream); }
-    void generate() { t0(1); hipLaunchKernelGGL(k_generate, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, C, P, Q.ext[0], Q.counts + Q_EXT); t1(); }
+    // per pass: G workgroups (= queue segments), each segment holds at most seg_cap entries
+    void pass_begin(const DParams &R_) {
+        R = R_;
+        const uint32_t chunks = (R.n_paths + BLOCK - 1) / BLOCK;
+        G = chunks < (uint32_t)grid_max ? chunks : (uint32_t)grid_max;
+        if (G < 1) G = 1;
+        seg_cap = ((chunks + G - 1) / G) * BLOCK;
+        (void)hipMemsetAsync(Q.counts, 0, (size_t)rows * Q_STRIDE * G * 4, stream);
+    }
+    void generate() { t0(1); hipLaunchKernelGGL(k_generate, dim3(G), dim3(BLOCK), 0, stream, R, S, C, P, Q, seg_cap); t1(); }
 
-    uint32_t *cnt(uint32_t it, int q) { return Q.counts + (size_t)it * Q_STRIDE + q; }
     template <int FEAT> void extend_t(uint32_t it) {
-        dim3 g(grid_for(R.n_paths)), b(BLOCK);
-        if (depth <= 16) hipLaunchKernelGGL((k_extend<FEAT, 16>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask);
-        else if (depth <= 32) hipLaunchKernelGGL((k_extend<FEAT, 32>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask);
-        else hipLaunchKernelGGL((k_extend<FEAT, 64>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask);
+        dim3 g(G), b(BLOCK);
+        if (depth <= 16 && geom4 <= 256) hipLaunchKernelGGL((k_extend<FEAT, 16, 256>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
+        else if (depth <= 16 && geom4 <= 1024) hipLaunchKernelGGL((k_extend<FEAT, 16, 1024>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
+        else if (depth <= 16) hipLaunchKernelGGL((k_extend<FEAT, 16, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
+        else if (depth <= 32) hipLaunchKernelGGL((k_extend<FEAT, 32, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
+        else hipLaunchKernelGGL((k_extend<FEAT, 64, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
     }
     void extend(uint32_t it) { t0(0); if (feat == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void connect_t(uint32_t it) {
-        dim3 g(grid_for(R.n_paths)), b(BLOCK);
-        if (depth <= 16) hipLaunchKernelGGL((k_connect<FEAT, 16>), g, b, 0, stream, R, sc, P, Q, it);
-        else if (depth <= 32) hipLaunchKernelGGL((k_connect<FEAT, 32>), g, b, 0, stream, R, sc, P, Q, it);
-        else hipLaunchKernelGGL((k_connect<FEAT, 64>), g, b, 0, stream, R, sc, P, Q, it);
+        dim3 g(G), b(BLOCK);
+        if (depth <= 16 && geom4 <= 256) hipLaunchKernelGGL((k_connect<FEAT, 16, 256>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
+        else if (depth <= 16 && geom4 <= 1024) hipLaunchKernelGGL((k_connect<FEAT, 16, 1024>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
+        else if (depth <= 16) hipLaunchKernelGGL((k_connect<FEAT, 16, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
+        else if (depth <= 32) hipLaunchKernelGGL((k_connect<FEAT, 32, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
+        else hipLaunchKernelGGL((k_connect<FEAT, 64, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
     }
     void connect(uint32_t it) { t0(0); if (feat == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void shade_t(uint32_t it, int kind) {
-        dim3 g(grid_for(R.n_paths)), b(BLOCK);
+        dim3 g(G), b(BLOCK);
         switch (kind) {
-            case 0: hipLaunchKernelGGL((k_shade<0, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
-            case 1: hipLaunchKernelGGL((k_shade<1, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
-            case 2: hipLaunchKernelGGL((k_shade<2, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
-            case 3: hipLaunchKernelGGL((k_shade<3, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
-            case 4: hipLaunchKernelGGL((k_shade<4, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
-            default: hipLaunchKernelGGL((k_shade<5, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it); break;
+            case 0: hipLaunchKernelGGL((k_shade<0, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
+            case 1: hipLaunchKernelGGL((k_shade<1, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
+            case 2: hipLaunchKernelGGL((k_shade<2, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
+            case 3: hipLaunchKernelGGL((k_shade<3, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
+            case 4: hipLaunchKernelGGL((k_shade<4, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
+            default: hipLaunchKernelGGL((k_shade<5, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
         }
     }
     void shade(uint32_t it, int kind) { t0(1); if (feat == FEAT_FULL) shade_t<FEAT_FULL>(it, kind); else shade_t<FEAT_SIMPLE>(it, kind); t1(); }
-    uint32_t read_count(uint32_t it, int q) { uint32_t v = 0; (void)hipMemcpyAsync(&v, cnt(it, q), 4, hipMemcpyDeviceToHost, stream); (void)hipStreamSynchronize(stream); return v; }
-    void read_counts(uint32_t *dst, uint32_t n_rows) { (void)hipMemcpyAsync(dst, Q.counts, (size_t)n_rows * Q_STRIDE * 4, hipMemcpyDeviceToHost, stream); if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE; }
+    void reduce_counts(uint32_t n_rows) { hipLaunchKernelGGL(k_reduce_counts, dim3(n_rows * Q_STRIDE), dim3(BLOCK), 0, stream, (const uint32_t *)Q.counts, G, (uint32_t *)ps->totals.p); }
+    uint32_t read_count(uint32_t it, int q) {
+        std::vector<uint32_t> seg(G);
+        (void)hipMemcpyAsync(seg.data(), Q.counts + ((size_t)it * Q_STRIDE + (size_t)q) * G, (size_t)G * 4, hipMemcpyDeviceToHost, stream);
+        if (hipStreamSynchronize(stream) != hipSuccess) { rc = PTRS_ERR_DEVICE; return 0; }
+        uint64_t t = 0; for (uint32_t v : seg) t += v;
+        return t > 0xffffffffull ? 0xffffffffu : (uint32_t)t;
+    }
+    void read_counts(uint32_t *dst, uint32_t n_rows) {
+        reduce_counts(n_rows);
+        (void)hipMemcpyAsync(dst, ps->totals.p, (size_t)n_rows * Q_STRIDE * 4, hipMemcpyDeviceToHost, stream);
+        if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE;
+    }
     void film(v4 *film_px, int32_t y0, int32_t y1) { t0(2); hipLaunchKernelGGL(k_film, dim3(grid_for((uint32_t)(y1 - y0) * (uint32_t)R.W)), dim3(BLOCK), 0, stream, R, S, P, (const float *)ps->table.p, film_px, y0, y1); t1(); }
     void export_samples(float *out) { t0(2); hipLaunchKernelGGL(k_export_samples, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, P, out); t1(); }
     void end(PtrsStats &st) {

@@ -30,7 +30,7 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(_HERE, "libptrs_hip.so")
+    so = os.environ.get("PTRS_LIB") or os.path.join(_HERE, "libptrs_hip.so")  # PTRS_LIB: A/B builds of the same library
     if not os.path.exists(so):
         raise PtrsError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
                         "There is no CPU fallback for the render path." % so)

@@ -101,7 +101,8 @@ struct HostBackend {
     void connect(uint32_t it) {
         for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) {
             CheckedStack stk = make_stack(); uint32_t nn = 0, nt = 0;
-            if (feat == FEAT_FULL) connect_item<FEAT_FULL>(sc, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE>(sc, P, Q.nee[i], stk, nn, nt);
+            GeomGlobal G; G.nodes = sc.nodes; G.tris = sc.tris;
+            if (feat == FEAT_FULL) connect_item<FEAT_FULL>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE>(sc, G, P, Q.nee[i], stk, nn, nt);
             nodes += nn; tris += nt;
         }
     }
