@@ -113,3 +113,56 @@ def triangle_soup(n_tris=20000, seed=1, resolution=(64, 64), extent=4.0, size=0.
     _add(s, rect, up @ m, mats[0], emission=[20.0, 20.0, 20.0])
     cam = look_at_camera([0.0, 0.5, 3.0 * extent], [0, 0, 0], [0, 1, 0], 40.0, resolution)
     return cam, s
+
+
+def synthetic_env_map(rows=32, cols=64, seed=3):
+    """Seeded HDR environment (sky gradient, ground, a small very bright sun): stands in for
+    data/abandoned_tank_farm_04_1k.hdr where the asset must not be read."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(rows, dtype=np.float32) + 0.5) / rows
+    u = (np.arange(cols, dtype=np.float32) + 0.5) / cols
+    sky = np.stack([0.3 + 0.5 * (1 - v), 0.5 + 0.4 * (1 - v), 0.9 + 0.0 * v], axis=-1)[:, None, :] * np.ones((1, cols, 1), np.float32)
+    ground = np.array([0.25, 0.2, 0.15], np.float32)
+    img = np.where((v < 0.55)[:, None, None], sky, ground).astype(np.float32)
+    img *= (1.0 + 0.2 * rng.uniform(-1, 1, (rows, cols, 1))).astype(np.float32)
+    su, sv = int(0.3 * cols), int(0.25 * rows)
+    img[sv:sv + 2, su:su + 2] = np.array([900.0, 800.0, 600.0], np.float32)
+    return img.astype(np.float32)
+
+
+def textured_env(resolution=(96, 64), env=None):
+    """Open scene lit by an environment map, with image textures (non-power-of-two: exercises the
+    Lanczos resample), a float roughness texture, a normal-mapped material and glass."""
+    from . import textures as tx
+    rng = np.random.default_rng(21)
+    s = RenderScene()
+    kd_img = (rng.uniform(40, 230, (12, 20, 3))).astype(np.uint8)
+    kd_tex = tx.spectrum_texture(s, kd_img, uvmap=(3.0, 3.0, 0.0, 0.0))
+    floor = s.add_material(abi.MAT_MATTE, [kd_tex])
+    rough_tex = tx.float_texture(s, rng.integers(20, 200, (16, 16)).astype(np.uint8), scale=0.8, uvmap=(2.0, 2.0, 0.0, 0.0))
+    disney = s.add_material(abi.MAT_DISNEY, [s.const_rgb([0.9, 0.6, 0.3]), s.const_f(0.6), s.const_f(1.5), rough_tex])
+    nm = np.zeros((16, 16, 3), np.uint8)
+    ang = rng.uniform(0, 2 * math.pi, (16, 16))
+    tilt = rng.uniform(0.0, 0.5, (16, 16))
+    nm[..., 0] = np.clip(127.5 * (1 + tilt * np.cos(ang)), 0, 255)
+    nm[..., 1] = np.clip(127.5 * (1 + tilt * np.sin(ang)), 0, 255)
+    nm[..., 2] = np.clip(127.5 * (1 + np.sqrt(1 - tilt ** 2)), 0, 255)
+    nm_tex = tx.normal_map_texture(s, nm, uvmap=(4.0, 2.0, 0.0, 0.0))
+    bumpy_inner = s.add_material(abi.MAT_MATTE, [s.const_rgb([0.7, 0.7, 0.75])])
+    bumpy = s.add_material(abi.MAT_NORMAL, [nm_tex], inner=bumpy_inner)
+    glass = s.add_material(abi.MAT_GLASS, [s.const_rgb([1, 1, 1]), s.const_rgb([1, 1, 1]), s.const_f(1.5)])
+    rect = gen_rectangle()
+    uv_rect = np.array([[0, 0], [1, 0], [0, 1], [1, 1]], dtype=np.float32)
+    rx = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)  # +z -> +y
+    _add(s, rect, rx @ _trs([4, 4, 1], [0, 0, 0]), floor, uv=uv_rect)
+    pos, nrm, idx, uv = uv_sphere(10, 20)
+    for center, r, mat in ([-1.3, 0.6, 0.0], 0.6, disney), ([0.0, 0.6, 0.3], 0.6, bumpy), ([1.3, 0.6, 0.0], 0.6, glass):
+        s.add_mesh((pos * np.float32(r) + np.array(center, np.float32)).astype(np.float32), idx, mat, normal=nrm, uv=uv)
+    # Mitsuba import's environment orientation (pathtracer/importer/mitsuba.rs:365-372): Euler(-pi/2,-pi/2,0) * scale(1,1,-1)
+    cr, sr = math.cos(-math.pi / 2), math.sin(-math.pi / 2)
+    rxm = np.array([[1, 0, 0, 0], [0, cr, -sr, 0], [0, sr, cr, 0], [0, 0, 0, 1]], np.float64)
+    rym = np.array([[cr, 0, sr, 0], [0, 1, 0, 0], [-sr, 0, cr, 0], [0, 0, 0, 1]], np.float64)
+    l2w = (rym @ rxm @ np.diag([1.0, 1.0, -1.0, 1.0])).astype(np.float32)
+    tx.add_infinite_light(s, synthetic_env_map() if env is None else env, light_to_world=l2w)
+    cam = look_at_camera([0.0, 1.4, 4.5], [0.0, 0.5, 0.0], [0, 1, 0], 40.0, resolution)
+    return cam, s

@@ -148,3 +148,10 @@ def test_full_size_properties(ptrs):
     cam.film.clear()
     integ.render(cam, scene)
     assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), a["rgb"].view(np.uint32))
+
+
+def test_textured_env_matches_oracle(ptrs, orc, scenes):
+    """FEAT_FULL kernels on the GPU: MIP-mapped image textures, normal mapping, environment light
+    (Distribution2D sampling, acos/atan2 stand-ins)."""
+    cam, scene = scenes.textured_env((96, 64))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)

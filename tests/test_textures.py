@@ -1,0 +1,45 @@
+"""Host-side texture / environment-light construction (pathtracer-rs_amd/textures.py)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+HDR = "/root/reference/data/abandoned_tank_farm_04_1k.hdr"
+
+
+@pytest.fixture(scope="module")
+def tx():
+    return importlib.import_module("pathtracer-rs_amd.textures")
+
+
+def test_mipmap_pyramid_shapes_and_box_filter(tx, ptrs):
+    img = np.random.default_rng(0).uniform(0, 1, (8, 16, 3)).astype(np.float32)
+    lv = tx.build_mipmap(img)
+    assert [l.shape for l in lv] == [(8, 16, 3), (4, 8, 3), (2, 4, 3), (1, 2, 3), (1, 1, 3)]
+    a = img
+    ref = (((a[0::2, 0::2] + a[0::2, 1::2]) + a[1::2, 0::2]) + a[1::2, 1::2]) * np.float32(0.25)
+    assert np.array_equal(lv[1], ref)
+    assert abs(float(lv[-1].mean()) - float(img.mean())) < 1e-5
+    # non power of two -> Lanczos resample to (16, 32) first (texture.rs:286-352)
+    lv2 = tx.build_mipmap(np.ones((12, 20, 1), np.float32))
+    assert lv2[0].shape == (16, 32, 1) and len(lv2) == 6
+
+
+def test_env_distribution_is_normalised(tx, ptrs, scenes):
+    s = ptrs.RenderScene()
+    tx.add_infinite_light(s, scenes.synthetic_env_map())
+    d = s.lights[0]["dist"]
+    assert (d["nu"], d["nv"]) == (128, 64)
+    assert np.allclose(d["cdf"][:, -1], 1.0, atol=1e-5) and np.all(np.diff(d["cdf"], axis=1) >= 0)
+    assert abs(d["marg_cdf"][-1] - 1.0) < 1e-5 and d["marg_func_int"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists(HDR), reason="reference asset not present on this box")
+def test_rgbe_reader_on_reference_asset(tx):
+    """data/abandoned_tank_farm_04_1k.hdr (`-Y 512 +X 1024`, RLE): decoded like image 0.23's
+    HdrDecoder (light.rs:331-346): c * 2^(e-136)."""
+    img = tx.read_rgbe(HDR)
+    assert img.shape == (512, 1024, 3) and img.dtype == np.float32
+    assert np.isfinite(img).all() and img.min() >= 0 and 1e3 < img.max() < 1e6
+    assert 0.2 < img.mean() < 2.0

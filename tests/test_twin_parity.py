@@ -76,3 +76,11 @@ def test_twin_sobol(orc):
     a, ia = twin.sobol_samples(p, px, py, sn, dm)
     b, ib = orc.sobol_samples(p, px, py, sn, dm)
     assert np.array_equal(ia, ib) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_twin_textured_env(scenes, orc):
+    """Image textures (resampled non-power-of-two pyramid, trilinear lookups at the camera vertex),
+    a normal-mapped material, a float roughness texture and the importance-sampled environment
+    light: the FEAT_FULL instantiations of the device code."""
+    cam, scene = scenes.textured_env((72, 48))
+    _compare(orc, cam, scene, 4, 15)
