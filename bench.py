@@ -33,9 +33,11 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SPP, DEPTH = 1024, 1024, 256, 15
 SCENE = os.path.join(ROOT, "tests", "golden", "cornell-box.xml")
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per k_extend launch from rocprofv3 PMC passes (profiles/): filled in once measured, else None
+TRAFFIC_PMC = None
 
 
-def cpu_baseline(pkg, rows=24):
+def cpu_baseline(pkg, rows=128):
     """Oracle (CPU port of the reference path) on rows [500, 500+rows) of the same frame."""
     from oracle import orc
 
@@ -77,10 +79,15 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("PTRS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals that share a GPU
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("pathtracer-rs_amd")
     par = importlib.import_module("pathtracer-rs_amd.parallel")
@@ -96,7 +103,13 @@ def main():
         film.zero_()
         st = integ.render_device(cam, scene, film.data_ptr(), stream=stream, row_begin=row_b, row_end=row_e, flags=flags)
         if world > 1:
-            par.gather_film_rows(film, H, rank, world)
+            if backend == "nccl":
+                par.gather_film_rows(film, H, rank, world)
+            else:  # CPU-staged gather (rehearsal only)
+                host = film.cpu()
+                par.gather_film_rows(host, H, rank, world)
+                if rank == 0:
+                    film.copy_(host)
         return st
 
     def sync():
@@ -127,7 +140,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
-    vals = torch.tensor([dt, float(rays), float(samples), ms_trace, ms_shade, ms_film, float(trace_launches), nodes_per_ray * c_rays, tris_per_ray * c_rays, float(c_rays)], dtype=torch.float64, device=dev)
+    vals = torch.tensor([dt, float(rays), float(samples), ms_trace, ms_shade, ms_film, float(trace_launches), nodes_per_ray * c_rays, tris_per_ray * c_rays, float(c_rays)], dtype=torch.float64,
+                        device=dev if backend == "nccl" else "cpu")
     if world > 1:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -152,8 +166,8 @@ def main():
             "config": {"workload": "cornell-box %dx%d spp=%d max_depth=%d, Lambertian + area light (BASELINE configs[1])" % (W, H, args.spp, args.depth),
                        "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world,
                        "ms_trace_per_step": ms_trace / args.steps, "ms_shade_per_step": float(vals[4]) / args.steps, "ms_film_per_step": float(vals[5]) / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_trace (BVH closest-hit / any-hit traversal)", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_PMC,
+                         "kernel": "k_extend + k_connect (BVH closest-hit / any-hit traversal; bytes and time summed over both)", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                          "avg_launch_ms": float(vals[3]) / max(float(vals[6]), 1.0), "launches": int(float(vals[6]))},
         }
         if world == 1 and not args.no_cpu_baseline:
