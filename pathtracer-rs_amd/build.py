@@ -43,6 +43,21 @@ def build(force=False, extra_flags=(), verbose=False):
     return LIB
 
 
+HEADLESS = os.path.join(HERE, "ptrs_headless")
+
+
+def build_host(force=False):
+    """C++ host mirror + headless CLI (g++, links libptrs_hip.so with rpath $ORIGIN)."""
+    srcs = [os.path.join(HERE, "host", f) for f in ("headless.cpp", "ptrs_host.cpp")]
+    deps = srcs + [os.path.join(HERE, "host", "ptrs_host.hpp"), LIB]
+    if not force and os.path.exists(HEADLESS) and all(os.path.getmtime(HEADLESS) >= os.path.getmtime(d) for d in deps):
+        return HEADLESS
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wextra", "-o", HEADLESS] + srcs +
+                          ["-L" + HERE, "-lptrs_hip", "-lz", "-Wl,-rpath,$ORIGIN"])
+    return HEADLESS
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True, extra_flags=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])
     print("built", LIB)
+    print("built", build_host(force="--force" in sys.argv))

@@ -1,0 +1,64 @@
+// ptrs_headless -- the reference's headless front-end over the HIP backend.
+//
+// Mirrors src/main.rs:35-145 (flag subset: SCENE, -o/--output DIR, -s/--samples, -r/--resolution WxH,
+// -d/--max_depth, --headless; the viewer flags are accepted and ignored) and src/headless.rs:222-229
+// (one-shot render, then film.to_rgba_image().save(DIR/render.png)).  Wiring follows main.rs:101-126:
+//   import -> SamplerBuilder::new(spp, film.get_sample_bounds()) -> PathIntegrator::new(.., max_depth)
+//   -> preprocess -> render -> save.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "ptrs_host.hpp"
+
+using namespace ptrs_host;
+
+static bool parse_resolution(const char *s, int &w, int &h) { // main.rs:23-33
+    const char *x = std::strchr(s, 'x');
+    if (!x || std::strchr(x + 1, 'x')) return false;
+    w = (int)std::strtof(std::string(s, x - s).c_str(), nullptr); h = (int)std::strtof(x + 1, nullptr);
+    return w > 0 && h > 0;
+}
+
+int main(int argc, char **argv) {
+    std::string scene_path, out_dir, dump_path;
+    int spp = 1, max_depth = 15, w = 640, h = 480; // DEFAULT_RESOLUTION common/mod.rs:14
+    bool have_out = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "error: %s needs a value\n", name); std::exit(2); } return argv[++i]; };
+        if (a == "-o" || a == "--output") { out_dir = need("--output"); have_out = true; }
+        else if (a == "-s" || a == "--samples") spp = std::atoi(need("--samples"));
+        else if (a == "-r" || a == "--resolution") { if (!parse_resolution(need("--resolution"), w, h)) { std::fprintf(stderr, "error: invalid resolution string\n"); return 2; } }
+        else if (a == "-d" || a == "--max_depth") { const char *v = need("--max_depth"); char *e; long d = std::strtol(v, &e, 10); max_depth = (*e == 0) ? (int)d : 20; } // main.rs:21,87-97
+        else if (a == "--dump-scene") dump_path = need("--dump-scene");
+        else if (a == "--headless" || a == "--default_lights") {}
+        else if (a == "-c" || a == "--camera" || a == "-l" || a == "--log_level" || a == "-m" || a == "--module_log" || a == "--server") (void)need(a.c_str());
+        else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "error: unknown flag %s\n", a.c_str()); return 2; }
+        else scene_path = a;
+    }
+    if (scene_path.empty() || (!have_out && dump_path.empty())) {
+        std::fprintf(stderr, "usage: ptrs_headless SCENE -o DIR [-s SPP] [-r WxH] [-d DEPTH] [--headless]\n");
+        return 2;
+    }
+    Camera camera; RenderScene scene; std::string err;
+    if (!import_scene(scene_path, w, h, camera, scene, err)) { std::fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+    if (!dump_path.empty()) { if (!dump_scene(dump_path, camera, scene)) { std::fprintf(stderr, "error: cannot write %s\n", dump_path.c_str()); return 1; } if (!have_out) return 0; }
+    int32_t sb[4];
+    camera.film.get_sample_bounds(sb);
+    PathIntegrator integrator(SamplerBuilder(spp, sb), max_depth, true);
+    integrator.preprocess(scene);
+    PtrsStats st{};
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = integrator.render(camera, scene, &st);
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != PTRS_OK) { std::fprintf(stderr, "error: render failed (%d): %s\n", rc, integrator.last_error.c_str()); return 1; }
+    std::fprintf(stderr, "INFO rendering took: %.3fs (%llu samples, %llu rays, %.1f Mray/s)\n", secs, (unsigned long long)st.samples,
+                 (unsigned long long)(st.rays_extension + st.rays_shadow + st.rays_mis), (double)(st.rays_extension + st.rays_shadow + st.rays_mis) / secs / 1e6);
+    const std::string out = out_dir + "/render.png"; // main.rs:70
+    if (!write_png_rgba8(out, camera.film.width, camera.film.height, camera.film.to_rgba_image(), err)) { std::fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+    std::fprintf(stderr, "INFO wrote %s\n", out.c_str());
+    return 0;
+}

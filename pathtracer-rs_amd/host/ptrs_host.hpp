@@ -1,0 +1,97 @@
+// ptrs_host.hpp -- C++ host mirror of the reference's API around the render() hot path.
+//
+// The reference is compiled code (Rust); no Rust toolchain exists in the build image, so the host
+// side above the C ABI (include/ptrs.h) is mirrored in C++ with the reference's names and
+// argument meaning:
+//   importer::import(path, resolution)                  src/common/importer/mod.rs:6-25 (.xml branch)
+//   Camera::new / get_camera                            src/common/mod.rs:33-62, importer/mitsuba.rs:685-710
+//   Film::{new, clear, get_sample_bounds, to_rgba_image} src/common/film.rs:132-251
+//   RenderScene::from_mitsuba                           src/pathtracer/importer/mitsuba.rs:84-428 (rgb-parameter subset)
+//   SamplerBuilder::new                                 src/pathtracer/sampler/sobol.rs:35-60
+//   PathIntegrator::{new, preprocess, render}           src/pathtracer/integrator.rs:230,250,536
+// The Python package (pathtracer-rs_amd/*.py) mirrors the same surface for tests and bench.py; both
+// produce bit-identical scene descriptions (tests/test_host_cpp.py).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrs.h"
+
+namespace ptrs_host {
+
+struct Film {
+    int width = 0, height = 0;
+    std::vector<PtrsFilmPixel> pixels; // row-major, accumulated (film.rs:113-129)
+    Film() = default;
+    Film(int w, int h) : width(w), height(h), pixels((size_t)w * h, PtrsFilmPixel{{0, 0, 0}, 0}) {}
+    void clear();                                   // film.rs:164-172
+    void get_sample_bounds(int32_t out[4]) const;   // film.rs:174-185: min_x, min_y, max_x, max_y
+    std::vector<uint8_t> to_rgba_image() const;     // film.rs:230-251 + spectrum.rs:95-102 (sRGB, +0.5, clamp)
+};
+
+struct Camera {
+    PtrsCamera abi{};
+    Film film;
+};
+
+struct Mesh {
+    std::vector<float> pos, normal, uv;
+    std::vector<uint32_t> indices;
+    int32_t material = -1;
+};
+
+struct RenderScene {
+    std::vector<Mesh> meshes;
+    std::vector<PtrsMaterial> materials;
+    std::vector<PtrsTexture> textures;
+    std::vector<PtrsLight> lights;
+    // flat description for ptrs_scene_create (valid while *this is alive and unmodified)
+    const PtrsSceneDesc &desc();
+    size_t num_triangles() const;
+
+private:
+    std::vector<PtrsMesh> abi_meshes_;
+    PtrsSceneDesc desc_{};
+};
+
+struct SamplerBuilder { // sobol.rs:25-60
+    int samples_per_pixel = 1;
+    int32_t sample_bounds[4] = {0, 0, 0, 0};
+    int resolution = 1;
+    uint32_t log_2_resolution = 0;
+    SamplerBuilder() = default;
+    SamplerBuilder(int spp, const int32_t bounds[4]);
+};
+
+class PathIntegrator { // integrator.rs:219-246
+public:
+    PathIntegrator(const SamplerBuilder &sb, int max_depth, bool show_progress_bar = false, int device = 0);
+    ~PathIntegrator();
+    void preprocess(const RenderScene &scene);          // integrator.rs:250-258
+    void toggle_progress_bar() { show_progress_bar_ = !show_progress_bar_; }
+    // integrator.rs:536-642 on the GPU; accumulates into camera.film.  Returns PTRS_OK or an error code.
+    int render(Camera &camera, RenderScene &scene, PtrsStats *stats = nullptr);
+    std::string last_error;
+
+private:
+    SamplerBuilder sb_;
+    int max_depth_;
+    float rr_threshold_ = 1.0f;
+    int rr_start_depth_ = 3;
+    bool rr_enable_ = true;
+    bool show_progress_bar_;
+    int device_;
+    PtrsScene *gpu_scene_ = nullptr;
+    const RenderScene *gpu_scene_src_ = nullptr;
+};
+
+// importer::import for Mitsuba XML (rectangle / cube shapes, twosided / diffuse / conductor /
+// roughconductor / dielectric / plastic / roughplastic bsdfs with rgb parameters, area emitters,
+// perspective sensor).  Returns false and fills err on failure.
+bool import_scene(const std::string &path, int res_w, int res_h, Camera &camera, RenderScene &scene, std::string &err);
+
+bool write_png_rgba8(const std::string &path, int w, int h, const std::vector<uint8_t> &rgba, std::string &err);
+bool dump_scene(const std::string &path, const Camera &camera, const RenderScene &scene);
+
+} // namespace ptrs_host
