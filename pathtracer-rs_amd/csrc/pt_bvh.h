@@ -6,7 +6,7 @@
 // earlier one, Q14).  The traversal stack is supplied by the caller: on gfx950 it lives in LDS
 // (one column per lane, see kernels.hip), on the host twin it is a local array.
 #pragma once
-#include "pt_tri.h"
+#include "pt_texture.h"
 
 namespace pt {
 
@@ -57,8 +57,18 @@ struct GeomLocal {
 // 64-lane wave the (expensive) triangle phase runs with most lanes active instead of once per
 // interior step.  Per ray the sequence of nodes and triangles visited is exactly that of the
 // reference loop (accelerator.rs:372-414), only the interleaving between lanes differs.
-template <bool ANY, class Stack, class Geom>
-PT_HD bool bvh_trace_g(const Geom &G, uint32_t n_nodes_total, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+// Alpha-mask test of an accepted candidate (shape.rs:227-244 / 470-521): the mask texture is looked up at
+// the interpolated uv with zero differentials; a value of exactly 0 rejects the hit.
+PT_HD bool alpha_rejects(const DScene &sc, uint32_t prim, int32_t alpha_tex, const TriHit &h) {
+    const v4 *q = reinterpret_cast<const v4 *>(sc.shade + prim);
+    const v4 f = q[5], g = q[6]; // uv0 in f.zw, uv1 in g.xy, uv2 in g.zw
+    const f2 uv = mk2(h.b0 * f.z + h.b1 * g.x + h.b2 * g.z, h.b0 * f.w + h.b1 * g.y + h.b2 * g.w);
+    return tex_eval<FEAT_FULL>(sc, alpha_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f).x == 0.0f;
+}
+
+template <bool ANY, bool ALPHA, class Stack, class Geom>
+PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+    const uint32_t n_nodes_total = sc.n_nodes;
     out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f; out.flags = 0;
     stack.clear(); // an any-hit query may have returned early and left entries behind
     if (n_nodes_total == 0) return false;
@@ -98,6 +108,7 @@ PT_HD bool bvh_trace_g(const Geom &G, uint32_t n_nodes_total, f3 o, f3 d, float 
             ++n_tris;
             TriHit h;
             if (tri_test(o, d, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
+                if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) continue;
                 if (ANY) { out.prim = 0; return true; }
                 hit = true; t_max = h.t;
                 out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
@@ -110,7 +121,7 @@ PT_HD bool bvh_trace_g(const Geom &G, uint32_t n_nodes_total, f3 o, f3 d, float 
 template <bool ANY, class Stack>
 PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
     GeomGlobal G; G.nodes = sc.nodes; G.tris = sc.tris;
-    return bvh_trace_g<ANY>(G, sc.n_nodes, o, d, t_max, stack, out, n_nodes, n_tris);
+    return bvh_trace_g<ANY, true>(G, sc, o, d, t_max, stack, out, n_nodes, n_tris);
 }
 
 struct LocalStack { // host twin / small fixed uses

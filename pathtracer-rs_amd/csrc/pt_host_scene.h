@@ -30,6 +30,7 @@ struct HostScene {
     std::vector<uint32_t> inf_lights;
     uint32_t max_depth = 0;
     bool kinds_present[7] = {false, false, false, false, false, false, false};
+    bool has_alpha = false;
 };
 
 namespace hostbvh {
@@ -175,7 +176,8 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
         const PtrsMesh &s = d.meshes[m];
         if (!s.pos || !s.indices) return bad("mesh without positions / indices");
         if (s.material < 0 || (uint32_t)s.material >= d.n_materials) return bad("mesh material out of range");
-        if (s.alpha_mask_tex >= 0) { err = "alpha-mask textures are not implemented in this build"; return PTRS_ERR_UNSUPPORTED; }
+        if (s.alpha_mask_tex >= 0 && !tex_ok(s.alpha_mask_tex, 1)) return bad("alpha mask must be a 1-channel texture");
+        if (s.alpha_mask_tex >= 0) H.has_alpha = true;
         int mi = s.material;
         for (int g = 0; g < 4 && H.mats[mi].kind == PTRS_MAT_NORMAL; ++g) mi = H.mats[mi].inner;
         const int bucket = H.mats[mi].kind;
@@ -205,7 +207,7 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             for (int k = 0; k < 3; ++k) for (int c = 0; c < 2; ++c) UV[k][c] = s.uv ? s.uv[2 * v[k] + c] : duv[k][c];
             T.material = s.material; T.light = -1; T.alpha_tex = s.alpha_mask_tex;
             T.flags = (s.normal ? TRI_HAS_NORMAL : 0u) | (s.tangent ? TRI_HAS_TANGENT : 0u) | (s.reverse_orientation ? TRI_REVERSE : 0u) | (s.transform_swaps_handedness ? TRI_SWAPS : 0u) |
-                      ((uint32_t)bucket << TRI_BUCKET_SHIFT);
+                      (s.alpha_mask_tex >= 0 ? TRI_HAS_ALPHA : 0u) | ((uint32_t)bucket << TRI_BUCKET_SHIFT);
             f3 dpdu, dpdv;
             if (!tri_dpduv(mk3(T.p0[0], T.p0[1], T.p0[2]), mk3(T.p1x, T.p1y, T.p1z), mk3(T.p2x, T.p2y, T.p2z), mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), dpdu, dpdv)) T.flags |= TRI_DEGENERATE;
         }

@@ -60,11 +60,16 @@ PT_HD void tri_point_normal(const TriRegs &T, float b0, float b1, float b2, f3 &
 }
 
 // Triangle::pdf_at_point (shape.rs:62-72): a single-triangle intersection from the offset origin
-PT_HD float tri_pdf_at_point(const TriRegs &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi) {
+template <int FEAT>
+PT_HD float tri_pdf_at_point(const DScene &sc, const TriRegs &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi) {
     f3 o = spawn_origin(ref_p, ref_err, ref_n, wi);
     TriHit h;
     if (!tri_test(o, wi, PT_INF, T.p0, T.p1, T.p2, h)) return 0.0f;
     if (T.flags & TRI_DEGENERATE) return 0.0f;
+    if ((FEAT & FEAT_ALPHA) && (T.flags & TRI_HAS_ALPHA)) { // Triangle::intersect's alpha test (shape.rs:227-244)
+        const f2 uv = mk2(h.b0 * T.uv0.x + h.b1 * T.uv1.x + h.b2 * T.uv2.x, h.b0 * T.uv0.y + h.b1 * T.uv1.y + h.b2 * T.uv2.y);
+        if (tex_eval<FEAT>(sc, T.alpha_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f).x == 0.0f) return 0.0f;
+    }
     f3 p, n;
     tri_point_normal(T, h.b0, h.b1, h.b2, p, n);
     return len2(ref_p - p) / (fabs_(dot(n, -wi)) * area);
@@ -105,7 +110,7 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
         f3 p, n, perr; f2 uv;
         tri_sample(T, u, p, n, perr, uv);
         o.wi = normalize(p - ref_p);
-        o.pdf = tri_pdf_at_point(T, L.area, ref_p, ref_err, ref_n, o.wi);
+        o.pdf = tri_pdf_at_point<FEAT>(sc, T, L.area, ref_p, ref_err, ref_n, o.wi);
         o.p1 = p; o.p1_err = perr; o.p1_n = n;
         f3 w = -o.wi;
         o.li = dot(n, w) > 0.0f ? (L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f)) : splat3(0.0f);
@@ -130,7 +135,7 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
 
 template <int FEAT>
 PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f3 w) {
-    if (L.kind == 2) return tri_pdf_at_point(load_tri_regs(&L.T), L.area, ref_p, ref_err, ref_n, w);
+    if (L.kind == 2) return tri_pdf_at_point<FEAT>(sc, load_tri_regs(&L.T), L.area, ref_p, ref_err, ref_n, w);
     if ((FEAT & FEAT_INFINITE) && L.kind == 3) {
         f3 wi = xform_vec(L.w2l, w);
         float theta = spherical_theta(wi), phi = spherical_phi(wi);

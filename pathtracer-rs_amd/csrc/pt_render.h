@@ -90,7 +90,7 @@ inline SampleGrid make_sample_grid(int32_t W, int32_t H, int32_t spp_in) {
 
 // FEAT_* bits (pt_texture.h) of a scene: only FEAT_SIMPLE (none) and FEAT_FULL (all) are instantiated
 inline int scene_features(const HostScene &H) {
-    bool any = !H.inf_lights.empty();
+    bool any = !H.inf_lights.empty() || H.has_alpha;
     for (const DTexture &t : H.texs) any = any || t.kind == PTRS_TEX_IMAGE;
     for (const DMaterial &m : H.mats) any = any || m.kind == PTRS_MAT_NORMAL;
     return any ? FEAT_FULL : FEAT_SIMPLE;

@@ -156,8 +156,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, DPaths P
         const v4 o = P.ray_o[pid], d = P.ray_d[pid];
         LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
         HitRec h;
-        if (GEOM > 0) bvh_trace_g<false>(GL, sc.n_nodes, xyz(o), xyz(d), o.w, stk, h, nn, nt);
-        else bvh_trace_g<false>(GG, sc.n_nodes, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+        if (GEOM > 0) bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+        else bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
         u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
         P.hit[pid] = r;
         const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);

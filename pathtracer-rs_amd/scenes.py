@@ -158,6 +158,17 @@ def textured_env(resolution=(96, 64), env=None):
     pos, nrm, idx, uv = uv_sphere(10, 20)
     for center, r, mat in ([-1.3, 0.6, 0.0], 0.6, disney), ([0.0, 0.6, 0.3], 0.6, bumpy), ([1.3, 0.6, 0.0], 0.6, glass):
         s.add_mesh((pos * np.float32(r) + np.array(center, np.float32)).astype(np.float32), idx, mat, normal=nrm, uv=uv)
+    # alpha-masked cards (shape.rs:227-244,471-521): a checker mask (0/1) on a matte quad and on an emissive quad
+    mask = s.add_texture(kind=abi.TEX_CHECKER, channels=1, value=0.0, value2=1.0, su=6.0, sv=4.0, du=0.05, dv=0.1)
+    card = s.add_material(abi.MAT_MATTE, [s.const_rgb([0.2, 0.7, 0.3])])
+    m1 = _trs([0.9, 0.6, 1.0], [-0.6, 0.9, 1.4], 20)
+    pos_c = np.array([transform_point(m1, p) for p in rect[0]], dtype=np.float32)
+    nrm_c = np.array([transform_vector(m1, n) for n in rect[1]], dtype=np.float32)
+    s.add_mesh(pos_c, rect[2], card, normal=nrm_c, uv=uv_rect, alpha_mask_tex=mask)
+    m2 = np.array([[1, 0, 0, 0], [0, 0, -1, 2.6], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32) @ _trs([0.7, 0.7, 1.0], [0.8, 0.0, 0.0])
+    pos_l = np.array([transform_point(m2, p) for p in rect[0]], dtype=np.float32)
+    nrm_l = np.array([transform_vector(m2, n) for n in rect[1]], dtype=np.float32)
+    s.add_mesh(pos_l, rect[2], card, normal=nrm_l, uv=uv_rect, emission_rgb=[6.0, 5.0, 4.0], alpha_mask_tex=mask)
     # Mitsuba import's environment orientation (pathtracer/importer/mitsuba.rs:365-372): Euler(-pi/2,-pi/2,0) * scale(1,1,-1)
     cr, sr = math.cos(-math.pi / 2), math.sin(-math.pi / 2)
     rxm = np.array([[1, 0, 0, 0], [0, cr, -sr, 0], [0, sr, cr, 0], [0, 0, 0, 1]], np.float64)

@@ -78,7 +78,7 @@ struct HostBackend {
             const uint32_t pid = q[i];
             const v4 o = P.ray_o[pid], d = P.ray_d[pid];
             CheckedStack stk = make_stack(); HitRec h; uint32_t nn = 0, nt = 0;
-            bvh_trace<false>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+            { GeomGlobal GX; GX.nodes = sc.nodes; GX.tris = sc.tris; bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GX, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt); }
             nodes += nn; tris += nt;
             u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
             const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
