@@ -36,27 +36,39 @@ PT_HD bool slab_test(const v4 &a, const v4 &b, f3 o, f3 inv, const bool neg[3], 
 }
 
 // Where traversal reads geometry from.  GeomGlobal: the HBM arrays (through L1/L2).  GeomLocal:
-// a 16-byte-vector copy [2 per node | 3 per triangle] -- on gfx950 the kernels stage small scenes
-// (Cornell: 59 nodes + 36 triangles = 3.6 KB) into LDS once per workgroup and walk them there.
+// a 16-byte-vector copy [4 per pair node | 3 per triangle] -- on gfx950 the kernels stage small scenes
+// (Cornell: 29 pair nodes + 36 triangles = 3.6 KB) into LDS once per workgroup and walk them there.
 struct GeomGlobal {
-    const DNode *nodes; const DTri *tris;
-    PT_MEM void node(uint32_t i, v4 &a, v4 &b) const { const v4 *q = reinterpret_cast<const v4 *>(nodes + i); a = q[0]; b = q[1]; }
+    const DNode2 *nodes2; const DTri *tris;
+    PT_MEM void node(uint32_t i, v4 &a, v4 &b, v4 &c, v4 &d) const { const v4 *q = reinterpret_cast<const v4 *>(nodes2 + i); a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { const v4 *q = reinterpret_cast<const v4 *>(tris + k); a = q[0]; b = q[1]; c = q[2]; }
 };
 struct GeomLocal {
     const v4 *nodes4; const v4 *tris4;
-    PT_MEM void node(uint32_t i, v4 &a, v4 &b) const { a = nodes4[2u * i]; b = nodes4[2u * i + 1u]; }
+    PT_MEM void node(uint32_t i, v4 &a, v4 &b, v4 &c, v4 &d) const { const v4 *q = nodes4 + 4u * i; a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { a = tris4[3u * k]; b = tris4[3u * k + 1u]; c = tris4[3u * k + 2u]; }
 };
 
-// ANY = false: closest hit (intersect); ANY = true: any hit (intersect_p).
-// Stack must provide push(uint32_t), pop(), empty() and clear().
-//
-// "while-while" form: each lane first walks interior nodes until it reaches a leaf that passes the
-// slab test (or runs out of nodes), and only then are the leaf's triangles tested -- so that on a
-// 64-lane wave the (expensive) triangle phase runs with most lanes active instead of once per
-// interior step.  Per ray the sequence of nodes and triangles visited is exactly that of the
-// reference loop (accelerator.rs:372-414), only the interleaving between lanes differs.
+// Bounds3::intersect_p_precomp (bounds.rs:190-232) on explicit box corners
+PT_HD bool slab_test6(float minx, float miny, float minz, float maxx, float maxy, float maxz, f3 o, f3 inv, const bool neg[3], float t_max) {
+    const float k = 1.0f + 2.0f * gamma_err(3);
+    float t_min = ((neg[0] ? maxx : minx) - o.x) * inv.x;
+    float t_mx = ((neg[0] ? minx : maxx) - o.x) * inv.x;
+    float ty_min = ((neg[1] ? maxy : miny) - o.y) * inv.y;
+    float ty_max = ((neg[1] ? miny : maxy) - o.y) * inv.y;
+    t_mx *= k; ty_max *= k;
+    if (t_min > ty_max || ty_min > t_mx) return false;
+    if (ty_min > t_min) t_min = ty_min;
+    if (ty_max < t_mx) t_mx = ty_max;
+    float tz_min = ((neg[2] ? maxz : minz) - o.z) * inv.z;
+    float tz_max = ((neg[2] ? minz : maxz) - o.z) * inv.z;
+    tz_max *= k;
+    if (t_min > tz_max || tz_min > t_mx) return false;
+    if (tz_min > t_min) t_min = tz_min;
+    if (tz_max < t_mx) t_mx = tz_max;
+    return (t_min < t_max) && (t_mx > 0.0f);
+}
+
 // Alpha-mask test of an accepted candidate (shape.rs:227-244 / 470-521): the mask texture is looked up at
 // the interpolated uv with zero differentials; a value of exactly 0 rejects the hit.
 PT_HD bool alpha_rejects(const DScene &sc, uint32_t prim, int32_t alpha_tex, const TriHit &h) {
@@ -66,40 +78,49 @@ PT_HD bool alpha_rejects(const DScene &sc, uint32_t prim, int32_t alpha_tex, con
     return tex_eval<FEAT_FULL>(sc, alpha_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f).x == 0.0f;
 }
 
+// ANY = false: closest hit (BVH::intersect); ANY = true: any hit (intersect_p), accelerator.rs:359-475.
+// Stack must provide push(uint32_t), pop(), empty() and clear().
+//
+// Per ray the leaves are visited in the reference's order: at an interior node the child on the
+// near side of the split axis first, the other one postponed on the stack.  Differences of form:
+//   * "while-while": a lane first descends to a leaf, then tests that leaf's triangles, so on a
+//     64-lane wave the expensive triangle phase runs with most lanes active;
+//   * both children's boxes are tested when the parent is fetched.  The reference tests the
+//     postponed child's box when it is popped, i.e. against a possibly smaller t_max; here a
+//     postponed subtree that has meanwhile fallen behind the closest hit is still entered and
+//     rejected one level further down (child boxes nest inside the parent's, so the same leaves
+//     are culled; a postponed LEAF has its triangles tested against t_max instead of its box).
+//     Only hits at exactly equal/rounded-equal t could resolve differently (BVH ties).
+// n_nodes counts child boxes tested, n_tris triangle tests.
 template <bool ANY, bool ALPHA, class Stack, class Geom>
 PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
-    const uint32_t n_nodes_total = sc.n_nodes;
     out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f; out.flags = 0;
     stack.clear(); // an any-hit query may have returned early and left entries behind
-    if (n_nodes_total == 0) return false;
-    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (sc.n_nodes2 == 0) return false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
-    const uint32_t NONE = 0xffffffffu;
-    uint32_t cur = 0; // node to visit next, NONE when the traversal is over
+    uint32_t cur = 0; // reference to process next (interior index or leaf), REF_NONE when done
     bool hit = false;
-    while (cur != NONE) {
-        // phase 1: descend until a leaf is accepted
-        uint32_t leaf_first = 0, leaf_count = 0;
-        while (cur != NONE) {
-            v4 a, b;
-            G.node(cur, a, b);
-            ++n_nodes;
-            if (slab_test(a, b, o, inv, neg, t_max)) {
-                const uint32_t offset = f2u(b.z), meta = f2u(b.w);
-                const uint32_t nprims = meta & 0xffffu;
-                if (nprims > 0) {
-                    leaf_first = offset; leaf_count = nprims;
-                    cur = stack.empty() ? NONE : stack.pop();
-                    break;
-                }
-                const uint32_t axis = (meta >> 16) & 0xffu;
-                if (neg[axis]) { stack.push(cur + 1); cur = offset; }
-                else { stack.push(offset); cur = cur + 1; }
-            } else {
-                cur = stack.empty() ? NONE : stack.pop();
-            }
+    while (cur != REF_NONE) {
+        // phase 1: descend through interior nodes until a leaf is reached
+        while (cur != REF_NONE && !(cur & REF_LEAF)) {
+            v4 a, b, c, e;
+            G.node(cur, a, b, c, e);
+            const uint32_t ref0 = f2u(e.x), ref1 = f2u(e.y), axis = f2u(e.z);
+            n_nodes += 2;
+            const bool h0 = slab_test6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t_max);
+            const bool h1 = ref1 != REF_NONE && slab_test6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t_max);
+            const bool second_first = axis < 3u && neg[axis];
+            const uint32_t near_ref = second_first ? ref1 : ref0, far_ref = second_first ? ref0 : ref1;
+            const bool near_hit = second_first ? h1 : h0, far_hit = second_first ? h0 : h1;
+            if (near_hit) { if (far_hit) stack.push(far_ref); cur = near_ref; }
+            else if (far_hit) cur = far_ref;
+            else cur = stack.empty() ? REF_NONE : stack.pop();
         }
+        if (cur == REF_NONE) break;
         // phase 2: the leaf's triangles, in order
+        const uint32_t leaf_first = cur & REF_FIRST_MASK, leaf_count = ((cur >> REF_COUNT_SHIFT) & 15u) + 1u;
+        cur = stack.empty() ? REF_NONE : stack.pop();
         for (uint32_t i = 0; i < leaf_count; ++i) {
             v4 ta, tb, tc;
             G.tri(leaf_first + i, ta, tb, tc);
@@ -120,7 +141,7 @@ PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max,
 
 template <bool ANY, class Stack>
 PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
-    GeomGlobal G; G.nodes = sc.nodes; G.tris = sc.tris;
+    GeomGlobal G; G.nodes2 = sc.nodes2; G.tris = sc.tris;
     return bvh_trace_g<ANY, true>(G, sc, o, d, t_max, stack, out, n_nodes, n_tris);
 }
 

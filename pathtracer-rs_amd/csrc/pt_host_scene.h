@@ -18,6 +18,7 @@
 namespace pt {
 
 struct HostScene {
+    std::vector<DNode2> nodes2; // traversal layout, derived from `nodes`
     std::vector<DNode> nodes;
     std::vector<DTri> tris;
     std::vector<DTriShade> shade;
@@ -274,6 +275,66 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
         order.swap(B.order);
         H.max_depth = B.max_depth;
         for (auto &nd : H.nodes) if ((nd.meta & 0xffffu) == 0 && (nd.meta >> 16) > 2) return bad("internal: bad axis");
+    }
+    // ---- pair nodes for traversal (pt_scene.h DNode2) ----
+    if (!H.nodes.empty()) {
+        struct Conv {
+            const std::vector<DNode> &n; std::vector<DNode2> &out;
+            static void box_of(const DNode &nd, float mn[3], float mx[3]) { mn[0] = nd.pmin[0]; mn[1] = nd.pmin[1]; mn[2] = nd.pmin[2]; mx[0] = nd.pmax0; mx[1] = nd.pmax1; mx[2] = nd.pmax2; }
+            static void set_child(DNode2 &d, int which, const float mn[3], const float mx[3], uint32_t ref) {
+                if (which == 0) { d.c0min[0] = mn[0]; d.c0min[1] = mn[1]; d.c0min[2] = mn[2]; d.c0max0 = mx[0]; d.c0max1 = mx[1]; d.c0max2 = mx[2]; d.ref0 = ref; }
+                else { d.c1min0 = mn[0]; d.c1min1 = mn[1]; d.c1min2 = mn[2]; d.c1max[0] = mx[0]; d.c1max[1] = mx[1]; d.c1max[2] = mx[2]; d.ref1 = ref; }
+            }
+            // reference to a leaf range; ranges longer than REF_MAX_LEAF (only possible when many centroids
+            // coincide) become a balanced subtree of pair nodes that share the leaf's box and keep the triangle order
+            uint32_t leaf_ref(uint32_t first, uint32_t count, const float mn[3], const float mx[3]) {
+                if (count <= REF_MAX_LEAF) return REF_LEAF | ((count - 1u) << REF_COUNT_SHIFT) | first;
+                uint32_t me = (uint32_t)out.size();
+                out.push_back(DNode2());
+                DNode2 d; std::memset(&d, 0, sizeof(d));
+                const uint32_t half = count / 2u; // balanced, order-preserving split
+                uint32_t r0 = leaf_ref(first, half, mn, mx);
+                uint32_t r1 = leaf_ref(first + half, count - half, mn, mx);
+                set_child(d, 0, mn, mx, r0); set_child(d, 1, mn, mx, r1); d.axis = 3; // axis 3: never "negative" -> first child first
+                out[me] = d;
+                return me;
+            }
+            uint32_t ref_of(uint32_t i) { // reference for binary-tree node i
+                const DNode &nd = n[i];
+                float mn[3], mx[3]; box_of(nd, mn, mx);
+                const uint32_t np = nd.meta & 0xffffu;
+                if (np) return leaf_ref(nd.offset, np, mn, mx);
+                uint32_t me = (uint32_t)out.size();
+                out.push_back(DNode2());
+                DNode2 d; std::memset(&d, 0, sizeof(d));
+                float amn[3], amx[3], bmn[3], bmx[3];
+                box_of(n[i + 1], amn, amx); box_of(n[nd.offset], bmn, bmx);
+                const uint32_t ra = ref_of(i + 1), rb = ref_of(nd.offset);
+                set_child(d, 0, amn, amx, ra); set_child(d, 1, bmn, bmx, rb); d.axis = (nd.meta >> 16) & 0xffu;
+                out[me] = d;
+                return me;
+            }
+        } conv{H.nodes, H.nodes2};
+        if (n_tris > REF_FIRST_MASK) return bad("too many triangles for the leaf reference encoding");
+        H.nodes2.reserve(H.nodes.size() / 2 + 2);
+        const uint32_t root = conv.ref_of(0);
+        if (root & REF_LEAF) { // the whole scene is one leaf: give it a parent whose second child is absent
+            DNode2 d; std::memset(&d, 0, sizeof(d));
+            float mn[3], mx[3]; Conv::box_of(H.nodes[0], mn, mx);
+            Conv::set_child(d, 0, mn, mx, root); d.ref1 = REF_NONE; d.axis = 3;
+            H.nodes2.insert(H.nodes2.begin(), d);
+        }
+        // stack bound = depth of the pair-node tree
+        std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 1u});
+        uint32_t depth2 = 0;
+        while (!st.empty()) {
+            auto [i, dp] = st.back(); st.pop_back();
+            depth2 = std::max(depth2, dp);
+            const DNode2 &nd = H.nodes2[i];
+            if (!(nd.ref0 & REF_LEAF)) st.push_back({nd.ref0, dp + 1});
+            if (nd.ref1 != REF_NONE && !(nd.ref1 & REF_LEAF)) st.push_back({nd.ref1, dp + 1});
+        }
+        H.max_depth = std::max(H.max_depth, depth2 + 1);
     }
     H.tris.resize(order.size());
     for (size_t k = 0; k < order.size(); ++k) {

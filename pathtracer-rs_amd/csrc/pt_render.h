@@ -131,8 +131,18 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     if (capacity < (uint64_t)g.NX) capacity = (uint64_t)g.NX;
     const uint64_t band_rows = (uint64_t)(srow1 - srow0);
     uint64_t rows_per_pass, samples_per_pass;
-    if (band_rows * (uint64_t)g.NX <= capacity) { rows_per_pass = band_rows; samples_per_pass = std::max<uint64_t>(1, std::min<uint64_t>(g.spp, capacity / (band_rows * (uint64_t)g.NX))); }
-    else { rows_per_pass = std::max<uint64_t>(1, capacity / (uint64_t)g.NX); samples_per_pass = 1; }
+    if (band_rows * (uint64_t)g.NX <= capacity) {
+        rows_per_pass = band_rows;
+        // balance the sample chunks: n passes of (almost) equal size instead of full passes plus a small tail
+        const uint64_t spp_max = std::max<uint64_t>(1, std::min<uint64_t>(g.spp, capacity / (band_rows * (uint64_t)g.NX)));
+        const uint64_t n_chunks = (g.spp + spp_max - 1) / spp_max;
+        samples_per_pass = (g.spp + n_chunks - 1) / n_chunks;
+    } else {
+        samples_per_pass = 1;
+        const uint64_t rows_max = std::max<uint64_t>(1, capacity / (uint64_t)g.NX);
+        const uint64_t n_chunks = (band_rows + rows_max - 1) / rows_max;
+        rows_per_pass = (band_rows + n_chunks - 1) / n_chunks;
+    }
     const uint64_t max_paths = rows_per_pass * (uint64_t)g.NX * samples_per_pass;
     if (max_paths >= 0xffffffffull) { err = "pass too large"; return PTRS_ERR_INVALID; }
 

@@ -18,6 +18,20 @@ struct alignas(16) DNode { // = PtrsBvhNode = LinearBVHNode (accelerator.rs:89-9
     uint32_t meta;      // num_prims (low 16 bits) | axis << 16
 };
 
+// Traversal node: one per INTERIOR node of the binary tree, holding both children's boxes and
+// references (4 x 16 B).  A reference is either an interior index or, with bit 31 set, a leaf:
+// bits 0..26 first triangle record, bits 27..30 triangle count - 1.  One fetch tests two boxes and
+// leaf nodes are never fetched.  axis = split axis of this node (near child = second iff dir[axis] < 0,
+// exactly the reference's visiting order, accelerator.rs:397-408).
+struct alignas(16) DNode2 {
+    float c0min[3]; float c0max0;      // v0
+    float c0max1, c0max2, c1min0, c1min1; // v1
+    float c1min2; float c1max[3];      // v2
+    uint32_t ref0, ref1, axis, pad;    // v3
+};
+static_assert(sizeof(DNode2) == 64, "node2");
+enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0xffffffffu, REF_FIRST_MASK = 0x07ffffffu, REF_COUNT_SHIFT = 27, REF_MAX_LEAF = 16 };
+
 enum : uint32_t { TRI_HAS_NORMAL = 1, TRI_HAS_TANGENT = 2, TRI_REVERSE = 8, TRI_SWAPS = 16, TRI_DEGENERATE = 32, TRI_HAS_ALPHA = 64,
                   TRI_IS_LIGHT = 128,        // the triangle carries a DiffuseAreaLight
                   TRI_BUCKET_SHIFT = 8 };    // bits 8..10: material bucket (kind of the innermost material)
@@ -73,7 +87,9 @@ struct alignas(16) DLight {
 };
 
 struct DScene {
-    const DNode *nodes;
+    const DNode2 *nodes2;   // traversal nodes (pairs)
+    uint32_t n_nodes2, pad0;
+    const DNode *nodes;     // the binary tree in the reference's 32-byte layout (kept for stats / export)
     const DTri *tris;
     const DTriShade *shade;
     const DMaterial *mats;

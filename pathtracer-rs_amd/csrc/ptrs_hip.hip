@@ -127,11 +127,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const uint32_t *__re
 // wavefront-ballot bucketing of surviving paths by material kind (one ballot + one atomic per wave
 // and bucket).
 // Stage the scene's nodes and leaf-ordered triangles into LDS as 16-byte vectors (GEOM = capacity in
-// vectors; host guarantees 2*n_nodes + 3*n_prims <= GEOM).
+// vectors; host guarantees 4*n_nodes2 + 3*n_prims <= GEOM).
 template <int GEOM>
 __device__ inline GeomLocal stage_geometry(const DScene &sc, v4 *lds) {
-    const uint32_t nn4 = 2u * sc.n_nodes, nt4 = 3u * sc.n_prims;
-    const v4 *gn = reinterpret_cast<const v4 *>(sc.nodes), *gt = reinterpret_cast<const v4 *>(sc.tris);
+    const uint32_t nn4 = 4u * sc.n_nodes2, nt4 = 3u * sc.n_prims;
+    const v4 *gn = reinterpret_cast<const v4 *>(sc.nodes2), *gt = reinterpret_cast<const v4 *>(sc.tris);
     for (uint32_t i = threadIdx.x; i < nn4; i += BLOCK) lds[i] = gn[i];
     for (uint32_t i = threadIdx.x; i < nt4; i += BLOCK) lds[nn4 + i] = gt[i];
     __syncthreads();
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, DPaths P
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
     __shared__ uint32_t lcount[8];
-    GeomLocal GL; GeomGlobal GG; GG.nodes = sc.nodes; GG.tris = sc.tris;
+    GeomLocal GL; GeomGlobal GG; GG.nodes2 = sc.nodes2; GG.tris = sc.tris;
     if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
     const uint32_t G = gridDim.x, b = blockIdx.x;
@@ -217,7 +217,7 @@ template <int FEAT, int DEPTH, int GEOM>
 __global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
-    GeomLocal GL; GeomGlobal GG; GG.nodes = sc.nodes; GG.tris = sc.tris;
+    GeomLocal GL; GeomGlobal GG; GG.nodes2 = sc.nodes2; GG.tris = sc.tris;
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom);
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
@@ -335,14 +335,14 @@ struct PtrsScene {
     int device = 0;
     HostScene H; // host copy kept for validation / stats
     DScene sc{};
-    DevBuf nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
+    DevBuf nodes2, nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
     // render workspace, grown on demand and reused across calls
     DevBuf ws[32];
     DevBuf counts, totals, stats, table, film_tmp, samples_tmp;
     std::vector<hipEvent_t> ev_pool;
     int n_cu = 256;
     ~PtrsScene() {
-        for (auto &b : {&nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
+        for (auto &b : {&nodes2, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
         for (auto &b : ws) b.release();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
@@ -380,7 +380,7 @@ struct HipBackend {
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_;
         grid_max = ps->n_cu * 8;
-        geom4 = getenv("PTRS_NO_LDS_GEOM") ? 0xffffffffu : 2u * sc.n_nodes + 3u * sc.n_prims;
+        geom4 = getenv("PTRS_NO_LDS_GEOM") ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims;
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
         void **slots16[] = {(void **)&P.ray_o, (void **)&P.ray_d, (void **)&P.beta, (void **)&P.L, (void **)&P.st, (void **)&P.hit, (void **)&P.pfilm, (void **)&P.nee0,
@@ -519,10 +519,11 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ps->n_cu = prop.multiProcessorCount;
     HostScene &H = ps->H;
-    if ((rc = upload(ps->nodes, H.nodes)) || (rc = upload(ps->tris, H.tris)) || (rc = upload(ps->shade, H.shade)) || (rc = upload(ps->mats, H.mats)) ||
+    if ((rc = upload(ps->nodes2, H.nodes2)) || (rc = upload(ps->nodes, H.nodes)) || (rc = upload(ps->tris, H.tris)) || (rc = upload(ps->shade, H.shade)) || (rc = upload(ps->mats, H.mats)) ||
         (rc = upload(ps->texs, H.texs)) || (rc = upload(ps->levels, H.levels)) || (rc = upload(ps->texdata, H.texdata)) || (rc = upload(ps->lights, H.lights)) ||
         (rc = upload(ps->distdata, H.distdata)) || (rc = upload(ps->inf, H.inf_lights))) { delete ps; return rc; }
     DScene &sc = ps->sc;
+    sc.nodes2 = (const DNode2 *)ps->nodes2.p; sc.n_nodes2 = (uint32_t)H.nodes2.size(); sc.pad0 = 0;
     sc.nodes = (const DNode *)ps->nodes.p; sc.tris = (const DTri *)ps->tris.p; sc.shade = (const DTriShade *)ps->shade.p; sc.mats = (const DMaterial *)ps->mats.p;
     sc.texs = (const DTexture *)ps->texs.p; sc.levels = (const DTexLevel *)ps->levels.p; sc.texdata = (const float *)ps->texdata.p; sc.lights = (const DLight *)ps->lights.p;
     sc.distdata = (const float *)ps->distdata.p; sc.inf_lights = (const uint32_t *)ps->inf.p;

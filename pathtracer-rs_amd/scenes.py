@@ -177,3 +177,91 @@ def textured_env(resolution=(96, 64), env=None):
     tx.add_infinite_light(s, synthetic_env_map() if env is None else env, light_to_world=l2w)
     cam = look_at_camera([0.0, 1.4, 4.5], [0.0, 0.5, 0.0], [0, 1, 0], 40.0, resolution)
     return cam, s
+
+
+# ---- Sponza-class stand-in (BASELINE configs[2] / [4]: the glTF asset is not available offline) ------
+def _grid(nu, nv):
+    """(nu+1)x(nv+1) lattice of uv in [0,1]^2 and its 2*nu*nv triangles."""
+    u, v = np.meshgrid(np.linspace(0, 1, nu + 1, dtype=np.float32), np.linspace(0, 1, nv + 1, dtype=np.float32), indexing="xy")
+    uv = np.stack([u.reshape(-1), v.reshape(-1)], axis=1).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="xy")
+    a = (j * (nu + 1) + i).reshape(-1)
+    idx = np.concatenate([np.stack([a, a + 1, a + nu + 2], axis=1), np.stack([a, a + nu + 2, a + nu + 1], axis=1)], axis=0).astype(np.uint32)
+    return uv, idx
+
+
+def _surface(scene, fn, nu, nv, material, uv_scale=(1.0, 1.0)):
+    """Adds the parametric surface fn(u, v) -> (pos, normal) tessellated nu x nv."""
+    uv, idx = _grid(nu, nv)
+    pos, nrm = fn(uv[:, 0].astype(np.float64), uv[:, 1].astype(np.float64))
+    scene.add_mesh(pos.astype(np.float32), idx, material, normal=nrm.astype(np.float32), uv=(uv * np.array(uv_scale, np.float32)).astype(np.float32))
+    return len(idx)
+
+
+def colonnade(resolution=(1280, 720), detail=1.0, seed=1, tex_size=1024):
+    """Procedural Sponza-class hall: tessellated floor / ceiling / walls, two rows of columns with
+    capitals and arches; Disney materials (metallic = 1, roughness 0.2 / 0.5) with a seeded image
+    base-colour texture; 1 directional + 4 point lights.  detail = 1 gives about 262k triangles
+    (BASELINE configs[2]: 1280x720, 64 spp, depth 15)."""
+    from . import textures as tx
+    rng = np.random.default_rng(seed)
+    s = RenderScene()
+    # seeded base-colour image: low-frequency colour noise under a checker
+    t = np.linspace(0, 1, tex_size, endpoint=False)
+    xx, yy = np.meshgrid(t, t)
+    base = np.stack([0.55 + 0.35 * np.sin(2 * np.pi * (3 * xx + rng.uniform())), 0.5 + 0.3 * np.sin(2 * np.pi * (5 * yy + rng.uniform())),
+                     0.45 + 0.3 * np.sin(2 * np.pi * (2 * (xx + yy) + rng.uniform()))], axis=-1)
+    checker = (((np.floor(xx * 16) + np.floor(yy * 16)) % 2) * 0.25 + 0.75)[..., None]
+    img8 = np.clip(255 * base * checker + rng.normal(0, 6, base.shape), 0, 255).astype(np.uint8)
+    col_tex = tx.spectrum_texture(s, img8)
+    mats = [s.add_material(abi.MAT_DISNEY, [col_tex, s.const_f(1.0), s.const_f(1.5), s.const_f(r)]) for r in (0.2, 0.5)]
+    stone = s.add_material(abi.MAT_DISNEY, [col_tex, s.const_f(0.0), s.const_f(1.5), s.const_f(0.6)])
+    LX, LY, LZ = 20.0, 10.0, 7.0
+    d = max(float(detail), 0.05) * 1.23  # detail = 1 -> ~262k triangles
+    n = lambda k: max(2, int(round(k * math.sqrt(d))))
+    tris = 0
+
+    def plane(origin, eu, ev, normal):
+        o, eu, ev, nn = (np.array(v, np.float64) for v in (origin, eu, ev, normal))
+        return lambda u, v: (o + u[:, None] * eu + v[:, None] * ev, np.tile(nn, (len(u), 1)))
+    tris += _surface(s, plane([-LX, 0, -LZ], [2 * LX, 0, 0], [0, 0, 2 * LZ], [0, 1, 0]), n(160), n(64), stone, (8, 3))
+    tris += _surface(s, plane([-LX, LY, LZ], [2 * LX, 0, 0], [0, 0, -2 * LZ], [0, -1, 0]), n(128), n(48), mats[1], (8, 3))
+    tris += _surface(s, plane([-LX, 0, -LZ], [0, 0, 2 * LZ], [0, LY, 0], [1, 0, 0]), n(64), n(48), stone, (3, 2))
+    tris += _surface(s, plane([LX, 0, LZ], [0, 0, -2 * LZ], [0, LY, 0], [-1, 0, 0]), n(64), n(48), stone, (3, 2))
+    tris += _surface(s, plane([LX, 0, -LZ], [-2 * LX, 0, 0], [0, LY, 0], [0, 0, 1]), n(128), n(48), stone, (8, 2))
+    ncol = 12
+    xs = np.linspace(-LX + 2.5, LX - 2.5, ncol)
+    for row, z in enumerate((-3.2, 3.2)):
+        for ci, x in enumerate(xs):
+            r, h = 0.55, 6.0
+
+            def shaft(u, v, x=x, z=z):
+                th = 2 * np.pi * u
+                rr = r * (1.0 + 0.06 * np.cos(16 * th)) * (1.0 - 0.08 * v)
+                p = np.stack([x + rr * np.cos(th), h * v, z + rr * np.sin(th)], axis=1)
+                nn = np.stack([np.cos(th), 0.08 * np.ones_like(th), np.sin(th)], axis=1)
+                return p, nn / np.linalg.norm(nn, axis=1, keepdims=True)
+            tris += _surface(s, shaft, n(44), n(44), mats[(ci + row) % 2], (2, 4))
+
+            def capital(u, v, x=x, z=z):
+                th, ph = 2 * np.pi * u, np.pi * v
+                nn = np.stack([np.sin(ph) * np.cos(th), np.cos(ph), np.sin(ph) * np.sin(th)], axis=1)
+                return np.array([x, h + 0.35, z]) + nn * np.array([0.85, 0.4, 0.85]), nn
+            tris += _surface(s, capital, n(30), n(30), mats[(ci + row + 1) % 2], (2, 1))
+        for ci in range(ncol - 1):
+            xa, xb = xs[ci], xs[ci + 1]
+
+            def arch(u, v, xa=xa, xb=xb, z=z):
+                a, th = np.pi * u, 2 * np.pi * v
+                R, rr = 0.5 * (xb - xa), 0.28
+                c = np.stack([0.5 * (xa + xb) - R * np.cos(a), 6.75 + 0.9 * R * np.sin(a), np.full_like(a, z)], axis=1)
+                radial = np.stack([-np.cos(a), 0.9 * np.sin(a), np.zeros_like(a)], axis=1)
+                radial /= np.linalg.norm(radial, axis=1, keepdims=True)
+                nn = radial * np.cos(th)[:, None] + np.array([0, 0, 1.0]) * np.sin(th)[:, None]
+                return c + rr * nn, nn
+            tris += _surface(s, arch, n(30), n(15), stone, (4, 1))
+    s.add_directional_light([0.25, 1.0, 0.35], [2.2, 2.0, 1.8])
+    for p in ([-12, 7.5, 0], [-4, 7.5, 0], [4, 7.5, 0], [12, 7.5, 0]):
+        s.add_point_light(p, [55.0, 50.0, 42.0])
+    cam = look_at_camera([-17.0, 3.2, 0.6], [6.0, 3.6, -0.4], [0, 1, 0], 60.0, resolution)
+    return cam, s

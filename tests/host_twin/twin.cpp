@@ -78,7 +78,7 @@ struct HostBackend {
             const uint32_t pid = q[i];
             const v4 o = P.ray_o[pid], d = P.ray_d[pid];
             CheckedStack stk = make_stack(); HitRec h; uint32_t nn = 0, nt = 0;
-            { GeomGlobal GX; GX.nodes = sc.nodes; GX.tris = sc.tris; bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GX, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt); }
+            { GeomGlobal GX; GX.nodes2 = sc.nodes2; GX.tris = sc.tris; bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GX, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt); }
             nodes += nn; tris += nt;
             u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
             const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
@@ -101,7 +101,7 @@ struct HostBackend {
     void connect(uint32_t it) {
         for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) {
             CheckedStack stk = make_stack(); uint32_t nn = 0, nt = 0;
-            GeomGlobal G; G.nodes = sc.nodes; G.tris = sc.tris;
+            GeomGlobal G; G.nodes2 = sc.nodes2; G.tris = sc.tris;
             if (feat == FEAT_FULL) connect_item<FEAT_FULL>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE>(sc, G, P, Q.nee[i], stk, nn, nt);
             nodes += nn; tris += nt;
         }
@@ -139,6 +139,7 @@ int twin_scene_create(const PtrsSceneDesc *d, void **out) {
     int rc = build_host_scene(*d, s->H, g_err);
     if (rc != PTRS_OK) { delete s; return rc; }
     HostScene &H = s->H; DScene &sc = s->sc;
+    sc.nodes2 = H.nodes2.data(); sc.n_nodes2 = (uint32_t)H.nodes2.size(); sc.pad0 = 0;
     sc.nodes = H.nodes.data(); sc.tris = H.tris.data(); sc.shade = H.shade.data(); sc.mats = H.mats.data(); sc.texs = H.texs.data();
     sc.levels = H.levels.data(); sc.texdata = H.texdata.data(); sc.lights = H.lights.data(); sc.distdata = H.distdata.data(); sc.inf_lights = H.inf_lights.data();
     sc.n_nodes = (uint32_t)H.nodes.size(); sc.n_prims = (uint32_t)H.tris.size(); sc.n_lights = (uint32_t)H.lights.size(); sc.n_inf = (uint32_t)H.inf_lights.size();
