@@ -33,8 +33,11 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SPP, DEPTH = 1024, 1024, 256, 15
 SCENE = os.path.join(ROOT, "tests", "golden", "cornell-box.xml")
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per k_extend launch from rocprofv3 PMC passes (profiles/): filled in once measured, else None
-TRAFFIC_PMC = None
+# HBM bytes per traversal-kernel launch (k_extend + k_connect) for the DEFAULT workload on one GPU, from two
+# separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; profiles/r01_v4_pmc_fetch_write.csv):
+# (83.67e6 + 150.86e6 KB fetched + 48.24e6 + 29.46e6 KB written) / 192 launches.  FETCH_SIZE is taken as
+# reported (gfx950 under-reports wide streaming reads by 2x; these are 16-byte gathers, uncalibrated).
+TRAFFIC_PMC_DEFAULT = (83.67e6 + 150.86e6 + 48.24e6 + 29.46e6) * 1024.0 / 192.0
 
 
 def cpu_baseline(pkg, rows=128):
@@ -187,7 +190,9 @@ def main():
             "config": {"workload": ("cornell-box %dx%d spp=%d max_depth=%d, Lambertian + area light (BASELINE configs[1])" if args.workload == "cornell" else "colonnade %dx%d spp=%d max_depth=%d, Disney metal + image texture + punctual lights (stand-in for BASELINE configs[2])") % (W, H, args.spp, args.depth),
                        "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world, "collective": ("none" if world == 1 else ("rccl gather of film row bands" if backend == "nccl" else backend + " gather (host-staged fallback)")),
                        "ms_trace_per_step": ms_trace / args.steps, "ms_shade_per_step": float(vals[4]) / args.steps, "ms_film_per_step": float(vals[5]) / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_PMC,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (TRAFFIC_PMC_DEFAULT if (world == 1 and args.workload == "cornell" and (args.spp, args.res, args.depth, args.paths_per_pass) == (SPP, WIDTH, DEPTH, 0)) else None),
+                         "algorithmic_bytes_per_launch": rays_rank0 * b_ray / max(float(vals[6]), 1.0),
                          "kernel": "k_extend + k_connect (BVH closest-hit / any-hit traversal; bytes and time summed over both)", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                          "avg_launch_ms": float(vals[3]) / max(float(vals[6]), 1.0), "launches": int(float(vals[6]))},
         }

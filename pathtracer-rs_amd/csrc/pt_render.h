@@ -95,6 +95,13 @@ inline int scene_features(const HostScene &H) {
     for (const DMaterial &m : H.mats) any = any || m.kind == PTRS_MAT_NORMAL;
     return any ? FEAT_FULL : FEAT_SIMPLE;
 }
+// Feature set the extension / connection kernels need: textured emission, environment light, alpha masks.
+// (A scene whose only image textures sit on materials can run the lean traversal kernels.)
+inline int scene_trace_features(const HostScene &H) {
+    bool any = !H.inf_lights.empty() || H.has_alpha;
+    for (const DLight &L : H.lights) any = any || (L.kind == PTRS_LIGHT_AREA && !L.ke_const);
+    return any ? FEAT_FULL : FEAT_SIMPLE;
+}
 
 template <class BE>
 int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_t bvh_depth, const PtrsCamera &cam, const PtrsRenderParams &prm,
@@ -127,7 +134,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     R.counters_on = (prm.flags & PTRS_FLAG_COUNTERS) ? 1u : 0u;
 
     // ---- pass planning ----------------------------------------------------------------------
-    uint64_t capacity = prm.paths_per_pass ? prm.paths_per_pass : (1ull << 24);
+    uint64_t capacity = prm.paths_per_pass ? prm.paths_per_pass : (1ull << 27); // up to ~35 GB of path state: HBM (288 GB) is plentiful, launches and tails are not free
     if (capacity < (uint64_t)g.NX) capacity = (uint64_t)g.NX;
     const uint64_t band_rows = (uint64_t)(srow1 - srow0);
     uint64_t rows_per_pass, samples_per_pass;
@@ -148,8 +155,8 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
 
     const uint32_t fixed_iters = (uint32_t)prm.max_depth + 1u; // li() runs at most max_depth+1 scene queries (Q7)
     const uint32_t max_iters = fixed_iters + 64u;              // head-room for null-BSDF skips (bounces -= 1)
-    const int feat = scene_features(sc_host_feat);
-    int rc = be.begin(sc, S, C, (uint32_t)max_paths, max_iters + 1u, bvh_depth, prm.flags, feat, err);
+    const int feat = scene_features(sc_host_feat), feat_trace = scene_trace_features(sc_host_feat);
+    int rc = be.begin(sc, S, C, (uint32_t)max_paths, max_iters + 1u, bvh_depth, prm.flags, feat, feat_trace, err);
     if (rc != PTRS_OK) return rc;
 
     PtrsStats st;

@@ -354,7 +354,7 @@ struct HipBackend {
     PtrsScene *ps; hipStream_t stream; SobolDevice *sob;
     DScene sc; DSampler S; DCamera C; DParams R; DPaths P; DQueues Q;
     uint32_t cap = 0, rows = 0, depth = 0, flags = 0, kinds_mask = 0;
-    int feat = FEAT_FULL;
+    int feat = FEAT_FULL, feat_trace = FEAT_FULL;
     uint32_t geom4 = 0xffffffffu; // 16-byte vectors needed to hold nodes + triangles in LDS
     uint32_t G = 1, seg_cap = 0;  // segmented queues of the current pass
     int grid_max = 2048;
@@ -377,8 +377,8 @@ struct HipBackend {
     void t1() { if (flags & PTRS_FLAG_TIMING) { if (spans.back().b) (void)hipEventRecord(spans.back().b, stream); } }
     int grid_for(uint32_t n) const { uint32_t g = (n + BLOCK - 1) / BLOCK; if (g < 1) g = 1; return (int)(g > (uint32_t)grid_max ? (uint32_t)grid_max : g); }
 
-    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, std::string &err) {
-        sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_;
+    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
+        sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
         grid_max = ps->n_cu * 8;
         geom4 = getenv("PTRS_NO_LDS_GEOM") ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims;
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
@@ -419,7 +419,7 @@ struct HipBackend {
         else if (depth <= 32) hipLaunchKernelGGL((k_extend<FEAT, 32, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
         else hipLaunchKernelGGL((k_extend<FEAT, 64, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
     }
-    void extend(uint32_t it) { t0(0); if (feat == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
+    void extend(uint32_t it) { t0(0); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void connect_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
         if (depth <= 16 && geom4 <= 256) hipLaunchKernelGGL((k_connect<FEAT, 16, 256>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
@@ -428,7 +428,7 @@ struct HipBackend {
         else if (depth <= 32) hipLaunchKernelGGL((k_connect<FEAT, 32, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
         else hipLaunchKernelGGL((k_connect<FEAT, 64, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
     }
-    void connect(uint32_t it) { t0(0); if (feat == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
+    void connect(uint32_t it) { t0(0); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void shade_t(uint32_t it, int kind) {
         dim3 g(G), b(BLOCK);
         switch (kind) {

@@ -43,7 +43,7 @@ struct HostBackend {
     std::vector<std::vector<unsigned char>> pool;
     float table[256];
     uint32_t cap = 0, rows = 0;
-    int feat = FEAT_FULL;
+    int feat = FEAT_FULL, feat_trace = FEAT_FULL;
     uint64_t nodes = 0, tris = 0;
 
     const uint32_t *sobol_matrices() { return g_tables.matrices.data(); }
@@ -53,7 +53,8 @@ struct HostBackend {
 
     template <class T> T *alloc(size_t n) { pool.emplace_back(n * sizeof(T) + 64); return reinterpret_cast<T *>(pool.back().data()); }
 
-    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t, int feat_, std::string &) {
+    int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t, int feat_, int feat_trace_, std::string &) {
+        feat_trace = g_force_full ? FEAT_FULL : feat_trace_;
         stack_cap = bvh_depth <= 16 ? 16 : (bvh_depth <= 32 ? 32 : 64);
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; feat = g_force_full ? FEAT_FULL : feat_;
         gaussian_filter_table(table);
@@ -85,7 +86,7 @@ struct HostBackend {
             if (k >= 0) Q.mat[k][cnt(it, Q_MAT0 + k)++] = pid;
         }
     }
-    void extend(uint32_t it) { if (feat == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); }
+    void extend(uint32_t it) { if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); }
     void shade(uint32_t it, int kind) {
         const uint32_t *q = Q.mat[kind];
         uint32_t *next = Q.ext[(it + 1) & 1];
@@ -102,7 +103,7 @@ struct HostBackend {
         for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) {
             CheckedStack stk = make_stack(); uint32_t nn = 0, nt = 0;
             GeomGlobal G; G.nodes2 = sc.nodes2; G.tris = sc.tris;
-            if (feat == FEAT_FULL) connect_item<FEAT_FULL>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE>(sc, G, P, Q.nee[i], stk, nn, nt);
+            if (feat_trace == FEAT_FULL) connect_item<FEAT_FULL>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE>(sc, G, P, Q.nee[i], stk, nn, nt);
             nodes += nn; tris += nt;
         }
     }
