@@ -277,34 +277,43 @@ PT_HD ShadeResult shade_dispatch(int bucket, const DParams &R, const DSampler &S
     }
 }
 
-// film gather for one output pixel over the current pass.  table = 16x16 Gaussian filter table
-// (film.rs:133-144).  Sample-pixels are visited x-outer / y-inner, samples innermost, which is the
-// order of one reference tile (integrator.rs:567-611).
-PT_HD void film_item(const DParams &R, const DSampler &S, const DPaths &P, const float *table, v4 *film, int32_t x, int32_t y) {
+// One sample's contribution to output pixel (x, y): FilmTile::add_sample (film.rs:60-106) seen from the
+// pixel.  pf = p_film of the sample, L its radiance; returns false when the pixel is outside the sample's
+// filter footprint.
+PT_HD bool film_weight(float pfx, float pfy, int32_t x, int32_t y, const float *table, float &w) {
     const float radius = 2.0f, inv_r = 1.0f / radius;
+    const float pdx = pfx - 0.5f, pdy = pfy - 0.5f;
+    const int32_t p0x = (int32_t)ceil_(pdx - radius), p0y = (int32_t)ceil_(pdy - radius);
+    const int32_t p1x = (int32_t)(floor_(pdx + radius) + 1.0f), p1y = (int32_t)(floor_(pdy + radius) + 1.0f);
+    if (x < p0x || x >= p1x || y < p0y || y >= p1y) return false;
+    const float fx = fabs_(((float)x - pdx) * inv_r * 16.0f);
+    const float fy = fabs_(((float)y - pdy) * inv_r * 16.0f);
+    int32_t ix = (int32_t)floor_(fx); if (ix > 15) ix = 15;
+    int32_t iy = (int32_t)floor_(fy); if (iy > 15) iy = 15;
+    w = table[iy * 16 + ix];
+    return true;
+}
+
+// Film gather for one output pixel over the current pass (host-twin form; the gfx950 kernel k_film does
+// the same sums in the same order from LDS tiles).  table = 16x16 Gaussian filter table (film.rs:133-144).
+// Order of accumulation: sample index outermost, then sample-pixel x, then y -- deterministic and
+// independent of bands / tiles.  (The reference's own order depends on tile scheduling, film.rs:213-228.)
+PT_HD void film_item(const DParams &R, const DSampler &S, const DPaths &P, const float *table, v4 *film, int32_t x, int32_t y) {
     v4 acc = film[(size_t)y * (size_t)R.W + (size_t)x];
     const uint32_t npix = (uint32_t)(R.row1 - R.row0) * (uint32_t)R.NX;
     const uint32_t ns = R.s1 - R.s0;
-    for (int32_t qx = x - 2; qx <= x + 2; ++qx) {
-        int32_t sx = qx - S.min_x;
-        if (sx < 0 || sx >= R.NX) continue;
-        for (int32_t qy = y - 2; qy <= y + 2; ++qy) {
-            int32_t sy = qy - S.min_y;
-            if (sy < R.row0 || sy >= R.row1) continue;
-            uint32_t base = (uint32_t)(sy - R.row0) * (uint32_t)R.NX + (uint32_t)sx;
-            for (uint32_t k = 0; k < ns; ++k) {
-                uint32_t pid = k * npix + base;
-                v4 pf = P.pfilm[pid];
-                float pdx = pf.x - 0.5f, pdy = pf.y - 0.5f;
-                int32_t p0x = (int32_t)ceil_(pdx - radius), p0y = (int32_t)ceil_(pdy - radius);
-                int32_t p1x = (int32_t)(floor_(pdx + radius) + 1.0f), p1y = (int32_t)(floor_(pdy + radius) + 1.0f);
-                if (x < p0x || x >= p1x || y < p0y || y >= p1y) continue;
-                float fx = fabs_(((float)x - pdx) * inv_r * 16.0f);
-                float fy = fabs_(((float)y - pdy) * inv_r * 16.0f);
-                int32_t ix = (int32_t)floor_(fx); if (ix > 15) ix = 15;
-                int32_t iy = (int32_t)floor_(fy); if (iy > 15) iy = 15;
-                float w = table[iy * 16 + ix];
-                v4 Lv = P.L[pid];
+    for (uint32_t k = 0; k < ns; ++k) {
+        for (int32_t qx = x - 2; qx <= x + 2; ++qx) {
+            const int32_t sx = qx - S.min_x;
+            if (sx < 0 || sx >= R.NX) continue;
+            for (int32_t qy = y - 2; qy <= y + 2; ++qy) {
+                const int32_t sy = qy - S.min_y;
+                if (sy < R.row0 || sy >= R.row1) continue;
+                const uint32_t pid = k * npix + (uint32_t)(sy - R.row0) * (uint32_t)R.NX + (uint32_t)sx;
+                const v4 pf = P.pfilm[pid];
+                float w;
+                if (!film_weight(pf.x, pf.y, x, y, table, w)) continue;
+                const v4 Lv = P.L[pid];
                 acc.x += Lv.x * w; acc.y += Lv.y * w; acc.z += Lv.z * w; acc.w += w;
             }
         }

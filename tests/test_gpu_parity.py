@@ -164,3 +164,16 @@ def test_colonnade_matches_oracle(ptrs, orc, scenes):
     cam, scene = scenes.colonnade((160, 90))
     assert 240000 < scene.num_triangles() < 290000
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15)
+
+
+def test_film_matches_twin_bitwise(ptrs, orc):
+    """The film kernel (LDS-tiled gather) forms every pixel's sums in the same order as the host twin's
+    film_item (sample index, then sample-pixel x, then y), so the accumulators agree bit for bit --
+    a stricter check of the film path than the 1e-5 comparison with the oracle's tile order."""
+    import twin
+    cam, scene = ptrs.import_scene(CORNELL, (70, 45))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(8, cam.film.get_sample_bounds()), 6, paths_per_pass=40000)
+    integ.render(cam, scene)
+    ft, _, _ = twin.TwinScene(scene).render(cam, orc.make_params(70, 45, 8, 6, paths_per_pass=40000))
+    assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ft["rgb"].view(np.uint32))
+    assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), ft["weight"].view(np.uint32))
