@@ -52,13 +52,34 @@ def cpu_baseline(pkg, rows=128):
     _, _, st = o.render(cam, p, n_threads=cores)
     dt = time.time() - t
     rays = st.rays_extension + st.rays_shadow + st.rays_mis
+    # the same port on one thread (the reference's `disable_rayon` feature), 2 rows
+    p1 = orc.make_params(WIDTH, HEIGHT, SPP, DEPTH, row_begin=500, row_end=502)
+    t = time.time()
+    _, _, st1 = o.render(cam, p1, n_threads=1)
+    dt1 = time.time() - t
+    rays1 = st1.rays_extension + st1.rays_shadow + st1.rays_mis
     return {
         "value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "single_thread_mray_s": rays1 / dt1 / 1e6, "single_thread_sample": "rows 500..502, %d rays, %.1f s" % (rays1, dt1),
         "msample_per_s": st.samples / dt / 1e6,
         "sample": "output rows 500..%d of the 1024x1024/256spp/depth-15 Cornell frame (%d li() samples, %d rays, %.1f s, %d threads, 16x16 tiles, dynamic queue)"
                   % (500 + rows, st.samples, rays, dt, cores),
         "nodes_per_ray": st.nodes_visited / max(rays, 1), "tris_per_ray": st.tris_tested / max(rays, 1),
     }
+
+
+def hbm_copy_gbs(torch, dev, nbytes=1 << 32, reps=5):
+    """Measured device-to-device copy rate (read + write bytes / time): the practical HBM ceiling on this box."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -71,7 +92,7 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--paths-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="cornell", choices=["cornell", "colonnade"],
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "colonnade", "classroom"],
                     help="cornell = BASELINE configs[1] (the headline); colonnade = synthetic stand-in for configs[2] (Sponza glTF is not available offline): 1280x720, 64 spp")
     args = ap.parse_args()
 
@@ -114,6 +135,12 @@ def main():
         if args.spp == SPP:
             args.spp = 64
         cam, scene = scenes.colonnade((W, H))
+    elif args.workload == "classroom":
+        scenes = importlib.import_module("pathtracer-rs_amd.scenes")
+        W, H = 1920, 1080
+        if args.spp == SPP:
+            args.spp = 128
+        cam, scene = scenes.classroom((W, H))
     else:
         W = H = args.res
         cam, scene = pkg.import_scene(SCENE, (W, H))
@@ -183,18 +210,20 @@ def main():
         # rank 0's own kernel: its rays x algorithmic bytes / its summed k_trace time
         achieved = (rays_rank0 * b_ray) / (float(vals[3]) * 1e-3) / 1e9 if float(vals[3]) > 0 else 0.0
         out = {
-            "metric": "Mray/s, %s %dx%d, %d spp, depth %d (Msample/s in config)" % ("Cornell Box" if args.workload == "cornell" else "colonnade (Sponza-class stand-in, %d triangles)" % scene.num_triangles(), W, H, args.spp, args.depth),
+            "metric": "Mray/s, %s %dx%d, %d spp, depth %d (Msample/s in config)" % ("Cornell Box" if args.workload == "cornell" else "%s (%s-class stand-in, %d triangles)" % (args.workload, "Sponza" if args.workload == "colonnade" else "Classroom", scene.num_triangles()), W, H, args.spp, args.depth),
             "value": rays / dt / 1e6, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (data/cornell-box.xml as parsed, deterministic Sobol sequence)",
-            "config": {"workload": ("cornell-box %dx%d spp=%d max_depth=%d, Lambertian + area light (BASELINE configs[1])" if args.workload == "cornell" else "colonnade %dx%d spp=%d max_depth=%d, Disney metal + image texture + punctual lights (stand-in for BASELINE configs[2])") % (W, H, args.spp, args.depth),
+            "config": {"workload": ("cornell-box %dx%d spp=%d max_depth=%d, Lambertian + area light (BASELINE configs[1])" if args.workload == "cornell" else ("colonnade %dx%d spp=%d max_depth=%d, Disney metal + image texture + punctual lights (stand-in for BASELINE configs[2])" if args.workload == "colonnade" else "classroom %dx%d spp=%d max_depth=%d, glass + Disney dielectric + HDR environment light (stand-in for BASELINE configs[3])")) % (W, H, args.spp, args.depth),
                        "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world, "collective": ("none" if world == 1 else ("rccl gather of film row bands" if backend == "nccl" else backend + " gather (host-staged fallback)")),
                        "ms_trace_per_step": ms_trace / args.steps, "ms_shade_per_step": float(vals[4]) / args.steps, "ms_film_per_step": float(vals[5]) / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (TRAFFIC_PMC_DEFAULT if (world == 1 and args.workload == "cornell" and (args.spp, args.res, args.depth, args.paths_per_pass) == (SPP, WIDTH, DEPTH, 0)) else None),
                          "algorithmic_bytes_per_launch": rays_rank0 * b_ray / max(float(vals[6]), 1.0),
                          "kernel": "k_extend + k_connect (BVH closest-hit / any-hit traversal; bytes and time summed over both)", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
-                         "avg_launch_ms": float(vals[3]) / max(float(vals[6]), 1.0), "launches": int(float(vals[6]))},
+                         "avg_launch_ms": float(vals[3]) / max(float(vals[6]), 1.0), "launches": int(float(vals[6])),
+                         # path-state traffic of the wavefront design, reported apart from the traversal figure
+                         "b_state_bytes_per_path_round": 224, "hbm_copy_measured_gbs": hbm_copy_gbs(torch, dev)},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cornell":
             out["cpu_baseline"] = cpu_baseline(pkg)

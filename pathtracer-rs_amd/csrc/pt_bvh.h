@@ -49,8 +49,10 @@ struct GeomLocal {
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { a = tris4[3u * k]; b = tris4[3u * k + 1u]; c = tris4[3u * k + 2u]; }
 };
 
-// Bounds3::intersect_p_precomp (bounds.rs:190-232) on explicit box corners
-PT_HD bool slab_test6(float minx, float miny, float minz, float maxx, float maxy, float maxz, f3 o, f3 inv, const bool neg[3], float t_max) {
+// Bounds3::intersect_p_precomp (bounds.rs:190-232) on explicit box corners, split in two: everything
+// that does not depend on ray.t_max (the per-axis interval tests and `t_max_box > 0`) is decided here
+// and the entry distance returned; the caller finishes the test with `t_entry < ray.t_max`.
+PT_HD bool slab_entry6(float minx, float miny, float minz, float maxx, float maxy, float maxz, f3 o, f3 inv, const bool neg[3], float &t_entry) {
     const float k = 1.0f + 2.0f * gamma_err(3);
     float t_min = ((neg[0] ? maxx : minx) - o.x) * inv.x;
     float t_mx = ((neg[0] ? minx : maxx) - o.x) * inv.x;
@@ -66,7 +68,8 @@ PT_HD bool slab_test6(float minx, float miny, float minz, float maxx, float maxy
     if (t_min > tz_max || tz_min > t_mx) return false;
     if (tz_min > t_min) t_min = tz_min;
     if (tz_max < t_mx) t_mx = tz_max;
-    return (t_min < t_max) && (t_mx > 0.0f);
+    t_entry = t_min;
+    return t_mx > 0.0f;
 }
 
 // Alpha-mask test of an accepted candidate (shape.rs:227-244 / 470-521): the mask texture is looked up at
@@ -79,18 +82,18 @@ PT_HD bool alpha_rejects(const DScene &sc, uint32_t prim, int32_t alpha_tex, con
 }
 
 // ANY = false: closest hit (BVH::intersect); ANY = true: any hit (intersect_p), accelerator.rs:359-475.
-// Stack must provide push(uint32_t), pop(), empty() and clear().
+// Stack must provide push(ref, t_entry), pop(ref&, t_entry&), empty() and clear().
 //
 // Per ray the leaves are visited in the reference's order: at an interior node the child on the
 // near side of the split axis first, the other one postponed on the stack.  Differences of form:
 //   * "while-while": a lane first descends to a leaf, then tests that leaf's triangles, so on a
 //     64-lane wave the expensive triangle phase runs with most lanes active;
-//   * both children's boxes are tested when the parent is fetched.  The reference tests the
-//     postponed child's box when it is popped, i.e. against a possibly smaller t_max; here a
-//     postponed subtree that has meanwhile fallen behind the closest hit is still entered and
-//     rejected one level further down (child boxes nest inside the parent's, so the same leaves
-//     are culled; a postponed LEAF has its triangles tested against t_max instead of its box).
-//     Only hits at exactly equal/rounded-equal t could resolve differently (BVH ties).
+//   * both children's boxes are read with the parent (pair nodes).  The reference tests a postponed
+//     child's box only when it is popped, against the t_max of that moment (accelerator.rs:372,
+//     bounds.rs:231).  Of that test only the last comparison `t_entry < ray.t_max` depends on t_max, so
+//     the postponed child is stacked together with its entry distance and the comparison is redone
+//     when it is popped: the same subtrees are entered as in the reference, which matters when two
+//     coincident surfaces compete at (rounded-)equal t.
 // n_nodes counts child boxes tested, n_tris triangle tests.
 template <bool ANY, bool ALPHA, class Stack, class Geom>
 PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
@@ -108,19 +111,22 @@ PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max,
             G.node(cur, a, b, c, e);
             const uint32_t ref0 = f2u(e.x), ref1 = f2u(e.y), axis = f2u(e.z);
             n_nodes += 2;
-            const bool h0 = slab_test6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t_max);
-            const bool h1 = ref1 != REF_NONE && slab_test6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t_max);
+            float t0 = 0.0f, t1 = 0.0f;
+            const bool h0 = slab_entry6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t0) && t0 < t_max;
+            const bool h1 = ref1 != REF_NONE && slab_entry6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t1) && t1 < t_max;
             const bool second_first = axis < 3u && neg[axis];
             const uint32_t near_ref = second_first ? ref1 : ref0, far_ref = second_first ? ref0 : ref1;
             const bool near_hit = second_first ? h1 : h0, far_hit = second_first ? h0 : h1;
-            if (near_hit) { if (far_hit) stack.push(far_ref); cur = near_ref; }
+            if (near_hit) { if (far_hit) stack.push(far_ref, second_first ? t0 : t1); cur = near_ref; }
             else if (far_hit) cur = far_ref;
-            else cur = stack.empty() ? REF_NONE : stack.pop();
+            else {
+                cur = REF_NONE;
+                while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
+            }
         }
         if (cur == REF_NONE) break;
         // phase 2: the leaf's triangles, in order
         const uint32_t leaf_first = cur & REF_FIRST_MASK, leaf_count = ((cur >> REF_COUNT_SHIFT) & 15u) + 1u;
-        cur = stack.empty() ? REF_NONE : stack.pop();
         for (uint32_t i = 0; i < leaf_count; ++i) {
             v4 ta, tb, tc;
             G.tri(leaf_first + i, ta, tb, tc);
@@ -135,6 +141,8 @@ PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max,
                 out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
             }
         }
+        cur = REF_NONE;
+        while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
     }
     return hit;
 }
@@ -146,9 +154,9 @@ PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, Hi
 }
 
 struct LocalStack { // host twin / small fixed uses
-    uint32_t s[64]; int n = 0;
-    PT_MEM void push(uint32_t v) { s[n++] = v; }
-    PT_MEM uint32_t pop() { return s[--n]; }
+    uint32_t s[64]; float te[64]; int n = 0;
+    PT_MEM void push(uint32_t v, float t) { s[n] = v; te[n] = t; ++n; }
+    PT_MEM void pop(uint32_t &v, float &t) { --n; v = s[n]; t = te[n]; }
     PT_MEM bool empty() const { return n == 0; }
     PT_MEM void clear() { n = 0; }
 };

@@ -30,6 +30,7 @@ struct HostScene {
     std::vector<float> distdata;
     std::vector<uint32_t> inf_lights;
     uint32_t max_depth = 0;
+    uint32_t stack_bound = 0; // most entries the pair-node traversal can have stacked (= depth of the pair tree)
     bool kinds_present[7] = {false, false, false, false, false, false, false};
     bool has_alpha = false;
 };
@@ -335,6 +336,7 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             if (nd.ref1 != REF_NONE && !(nd.ref1 & REF_LEAF)) st.push_back({nd.ref1, dp + 1});
         }
         H.max_depth = std::max(H.max_depth, depth2 + 1);
+        H.stack_bound = depth2;
     }
     H.tris.resize(order.size());
     for (size_t k = 0; k < order.size(); ++k) {

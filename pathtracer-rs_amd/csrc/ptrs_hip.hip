@@ -4,7 +4,8 @@
 // grid (CUs x 8 workgroups of 256 threads = 4 wave64 per workgroup) and grid-strides over a queue
 // whose length it reads from device memory, so a whole pass is enqueued without host round trips.
 // Queue compaction uses one wave-aggregated atomic per wave (64-bit ballot + mbcnt prefix).
-// The traversal stack lives in LDS, one 4-byte column per lane (bank = lane % 32: conflict free).
+// The traversal stack lives in LDS, one column of 8-byte (node ref, entry distance) records per lane; on
+// trees deeper than the LDS column the excess spills to a per-thread column in global memory.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (bit-exact arithmetic, see pt_vec.h).
 #include <hip/hip_runtime.h>
@@ -74,11 +75,25 @@ __device__ inline void block_count(uint32_t *lds_counter, bool pred) {
 // counts[(row * Q_STRIDE + q) * G + b]
 __device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uint32_t G, uint32_t b) { return Q.counts + ((size_t)row * Q_STRIDE + (size_t)q) * G + b; }
 
-struct LdsStack { // column `threadIdx.x` of a [depth][BLOCK] LDS array
-    uint32_t *col;
+// Traversal stack: column `threadIdx.x` of a [D][BLOCK] LDS array of (ref, entry distance) records.
+// OVF: entries beyond D go to this thread's column of a global array (StackSpill), so deep trees keep
+// the LDS footprint -- and with it the occupancy -- of a 16-entry stack.
+struct StackSpill { uint2 *p; uint32_t stride; };
+template <int D, bool OVF>
+struct LdsStack {
+    uint2 *col; uint2 *ovf; uint32_t ovf_stride;
     int n;
-    __device__ inline void push(uint32_t v) { col[n * BLOCK] = v; ++n; }
-    __device__ inline uint32_t pop() { --n; return col[n * BLOCK]; }
+    __device__ inline void init(uint2 *lds, const StackSpill &sp) { col = lds + threadIdx.x; ovf = OVF ? sp.p + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr; ovf_stride = sp.stride; n = 0; }
+    __device__ inline void push(uint32_t v, float t) {
+        uint2 e; e.x = v; e.y = f2u(t);
+        if (!OVF || n < D) col[n * BLOCK] = e; else ovf[(size_t)(n - D) * ovf_stride] = e;
+        ++n;
+    }
+    __device__ inline void pop(uint32_t &v, float &t) {
+        --n;
+        const uint2 e = (!OVF || n < D) ? col[n * BLOCK] : ovf[(size_t)(n - D) * ovf_stride];
+        v = e.x; t = u2f(e.y);
+    }
     __device__ inline bool empty() const { return n == 0; }
     __device__ inline void clear() { n = 0; }
 };
@@ -103,18 +118,18 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCame
 }
 
 // Ray source: (ro, rd) indexed by path slot, ro.w = t_max.  ANY: write occl[pid]; else write hits[pid].
-template <bool ANY, int DEPTH>
-__global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ count,
+template <bool ANY, int DEPTH, bool OVF>
+__global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, StackSpill spill, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ count,
                                                  const v4 *__restrict__ ro, const v4 *__restrict__ rd, u4 *__restrict__ hits,
                                                  uint32_t *__restrict__ occl, float *__restrict__ tout, unsigned long long *stats, uint32_t counters_on) {
-    __shared__ uint32_t lds_stack[DEPTH * BLOCK];
+    __shared__ uint2 lds_stack[DEPTH * BLOCK];
     const uint32_t n = *count;
     const uint32_t stride = gridDim.x * BLOCK;
     uint32_t nn = 0, nt = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const uint32_t pid = queue ? queue[i] : i;
         const v4 o = ro[pid], d = rd[pid];
-        LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
+        LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
         HitRec h;
         const bool hit = bvh_trace<ANY>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
         if (ANY) occl[pid] = hit ? 1u : 0u;
@@ -139,9 +154,9 @@ __device__ inline GeomLocal stage_geometry(const DScene &sc, v4 *lds) {
     return G;
 }
 
-template <int FEAT, int DEPTH, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
-    __shared__ uint32_t lds_stack[DEPTH * BLOCK];
+template <int FEAT, int DEPTH, bool OVF, int GEOM>
+__global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
+    __shared__ uint2 lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
     __shared__ uint32_t lcount[8];
     GeomLocal GL; GeomGlobal GG; GG.nodes2 = sc.nodes2; GG.tris = sc.tris;
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, DPaths P
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
         const uint32_t pid = queue[i];
         const v4 o = P.ray_o[pid], d = P.ray_d[pid];
-        LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
+        LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
         HitRec h;
         if (GEOM > 0) bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
         else bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
@@ -213,9 +228,9 @@ __global__ __launch_bounds__(BLOCK, PTRS_SHADE_WAVES) void k_shade(DParams R, DS
 }
 
 // Shadow (any-hit) and MIS (closest-hit) queries of the pending NEE records, resolved into L.
-template <int FEAT, int DEPTH, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
-    __shared__ uint32_t lds_stack[DEPTH * BLOCK];
+template <int FEAT, int DEPTH, bool OVF, int GEOM>
+__global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
+    __shared__ uint2 lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
     GeomLocal GL; GeomGlobal GG; GG.nodes2 = sc.nodes2; GG.tris = sc.tris;
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom);
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, DPaths 
     const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
     uint32_t nn = 0, nt = 0;
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
-        LdsStack stk; stk.col = lds_stack + threadIdx.x; stk.n = 0;
+        LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
         if (GEOM > 0) connect_item<FEAT>(sc, GL, P, queue[i], stk, nn, nt);
         else connect_item<FEAT>(sc, GG, P, queue[i], stk, nn, nt);
     }
@@ -366,13 +381,16 @@ struct PtrsScene {
     HostScene H; // host copy kept for validation / stats
     DScene sc{};
     DevBuf nodes2, nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
+    DevBuf stack_spill;  // global part of the traversal stacks (trees deeper than the LDS column), one column per resident thread
+    StackSpill spill{nullptr, 0};
+    uint32_t stack_lds = 16; // LDS stack entries per lane: 8 when the tree allows it, else 16 (+ spill)
     // render workspace, grown on demand and reused across calls
     DevBuf ws[32];
     DevBuf counts, totals, stats, table, film_tmp, samples_tmp;
     std::vector<hipEvent_t> ev_pool;
     int n_cu = 256;
     ~PtrsScene() {
-        for (auto &b : {&nodes2, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
+        for (auto &b : {&stack_spill, &nodes2, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
         for (auto &b : ws) b.release();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
@@ -443,20 +461,28 @@ struct HipBackend {
 
     template <int FEAT> void extend_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
-        if (depth <= 16 && geom4 <= 256) hipLaunchKernelGGL((k_extend<FEAT, 16, 256>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
-        else if (depth <= 16 && geom4 <= 1024) hipLaunchKernelGGL((k_extend<FEAT, 16, 1024>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
-        else if (depth <= 16) hipLaunchKernelGGL((k_extend<FEAT, 16, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
-        else if (depth <= 32) hipLaunchKernelGGL((k_extend<FEAT, 32, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
-        else hipLaunchKernelGGL((k_extend<FEAT, 64, 0>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
+        const StackSpill sp = ps->spill;
+        const bool ovf = sp.p != nullptr;
+#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_extend<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, kinds_mask, seg_cap)
+        if (ps->stack_lds == 8) {
+            if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
+            else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
+            else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
+        } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
+#undef PTRS_LAUNCH
     }
     void extend(uint32_t it) { t0(0); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void connect_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
-        if (depth <= 16 && geom4 <= 256) hipLaunchKernelGGL((k_connect<FEAT, 16, 256>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
-        else if (depth <= 16 && geom4 <= 1024) hipLaunchKernelGGL((k_connect<FEAT, 16, 1024>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
-        else if (depth <= 16) hipLaunchKernelGGL((k_connect<FEAT, 16, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
-        else if (depth <= 32) hipLaunchKernelGGL((k_connect<FEAT, 32, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
-        else hipLaunchKernelGGL((k_connect<FEAT, 64, 0>), g, b, 0, stream, R, sc, P, Q, it, seg_cap);
+        const StackSpill sp = ps->spill;
+        const bool ovf = sp.p != nullptr;
+#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap)
+        if (ps->stack_lds == 8) {
+            if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
+            else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
+            else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
+        } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
+#undef PTRS_LAUNCH
     }
     void connect(uint32_t it) { t0(0); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void shade_t(uint32_t it, int kind) {
@@ -561,6 +587,16 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     sc.texs = (const DTexture *)ps->texs.p; sc.levels = (const DTexLevel *)ps->levels.p; sc.texdata = (const float *)ps->texdata.p; sc.lights = (const DLight *)ps->lights.p;
     sc.distdata = (const float *)ps->distdata.p; sc.inf_lights = (const uint32_t *)ps->inf.p;
     sc.n_nodes = (uint32_t)H.nodes.size(); sc.n_prims = (uint32_t)H.tris.size(); sc.n_lights = (uint32_t)H.lights.size(); sc.n_inf = (uint32_t)H.inf_lights.size();
+    // traversal stack: 8 LDS entries per lane for shallow pair trees (<= 12 levels: the last entries are hardly ever
+    // reached), else 16; what a deeper tree can stack beyond that spills to a global column per resident thread.  PTRS_STACK_LDS=8 forces the small
+    // LDS column (with spill) on any scene -- a test hook for the spill path.
+    const char *force = getenv("PTRS_STACK_LDS");
+    ps->stack_lds = (H.stack_bound <= 12 || (force && atoi(force) == 8)) ? 8u : 16u;
+    if (H.stack_bound > ps->stack_lds) {
+        const size_t threads = (size_t)ps->n_cu * 8 * BLOCK;
+        if ((rc = ps->stack_spill.ensure(threads * (size_t)(H.stack_bound - ps->stack_lds) * sizeof(uint2))) != PTRS_OK) { delete ps; return rc; }
+        ps->spill.p = (uint2 *)ps->stack_spill.p; ps->spill.stride = (uint32_t)threads;
+    }
     *out = ps;
     return PTRS_OK;
 }
@@ -641,15 +677,17 @@ int ptrs_trace_rays(PtrsScene *scene, uint32_t n, const float *rays, int32_t any
     if ((rc = upload(bo, ro)) || (rc = upload(bd, rd)) || (rc = bh.ensure((size_t)n * 16)) || (rc = bc.ensure(16)) || (rc = bs.ensure(CNT_NUM * 8)) || (rc = bt.ensure((size_t)n * 4))) { bo.release(); bd.release(); bh.release(); bc.release(); bs.release(); bt.release(); return rc; }
     hipError_t e = hipMemcpy(bc.p, &n, 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(bs.p, 0, CNT_NUM * 8);
-    const uint32_t depth = scene->H.max_depth;
-    dim3 g((n + BLOCK - 1) / BLOCK > 2048u ? 2048u : (n + BLOCK - 1) / BLOCK), b(BLOCK);
+    const uint32_t gmax = (uint32_t)scene->n_cu * 8u; // the spill columns are sized for this many workgroups
+    dim3 g((n + BLOCK - 1) / BLOCK > gmax ? gmax : (n + BLOCK - 1) / BLOCK), b(BLOCK);
     hipEvent_t ea, eb; (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
     (void)hipEventRecord(ea, nullptr);
 #define LAUNCH_T(ANYV)                                                                                                                                  \
     do {                                                                                                                                                \
-        if (depth <= 16) hipLaunchKernelGGL((k_trace<ANYV, 16>), g, b, 0, nullptr, scene->sc, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
-        else if (depth <= 32) hipLaunchKernelGGL((k_trace<ANYV, 32>), g, b, 0, nullptr, scene->sc, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
-        else hipLaunchKernelGGL((k_trace<ANYV, 64>), g, b, 0, nullptr, scene->sc, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
+        const StackSpill sp = scene->spill;                                                                                                             \
+        if (scene->stack_lds == 8 && !sp.p) hipLaunchKernelGGL((k_trace<ANYV, 8, false>), g, b, 0, nullptr, scene->sc, sp, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
+        else if (scene->stack_lds == 8) hipLaunchKernelGGL((k_trace<ANYV, 8, true>), g, b, 0, nullptr, scene->sc, sp, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
+        else if (!sp.p) hipLaunchKernelGGL((k_trace<ANYV, 16, false>), g, b, 0, nullptr, scene->sc, sp, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
+        else hipLaunchKernelGGL((k_trace<ANYV, 16, true>), g, b, 0, nullptr, scene->sc, sp, (const uint32_t *)nullptr, (const uint32_t *)bc.p, (const v4 *)bo.p, (const v4 *)bd.p, (u4 *)bh.p, (uint32_t *)bh.p, (float *)bt.p, (unsigned long long *)bs.p, 1u); \
     } while (0)
     if (any_hit) LAUNCH_T(true); else LAUNCH_T(false);
 #undef LAUNCH_T

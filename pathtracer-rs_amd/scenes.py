@@ -265,3 +265,107 @@ def colonnade(resolution=(1280, 720), detail=1.0, seed=1, tex_size=1024):
         s.add_point_light(p, [55.0, 50.0, 42.0])
     cam = look_at_camera([-17.0, 3.2, 0.6], [6.0, 3.6, -0.4], [0, 1, 0], 60.0, resolution)
     return cam, s
+
+
+# ---- Classroom-class stand-in (BASELINE configs[3]: glass + HDR environment light) -------------------
+def synthetic_env_map_1k(seed=5):
+    """512x1024 seeded HDR sky (same size class as abandoned_tank_farm_04_1k.hdr, which may not be read)."""
+    rows, cols = 512, 1024
+    small = synthetic_env_map(64, 128, seed)
+    img = np.repeat(np.repeat(small, rows // 64, axis=0), cols // 128, axis=1)
+    v = (np.arange(rows, dtype=np.float32) + 0.5) / rows
+    u = (np.arange(cols, dtype=np.float32) + 0.5) / cols
+    img = img * (1.0 + 0.15 * np.sin(40 * np.pi * u)[None, :, None] * np.cos(24 * np.pi * v)[:, None, None]).astype(np.float32)
+    return np.maximum(img, 0.0).astype(np.float32)
+
+
+def classroom(resolution=(1920, 1080), detail=1.0, seed=2, tex_size=512, env=None):
+    """Procedural classroom-class room: tessellated floor / ceiling / three walls, a window wall made of piers
+    with solid glass panes (KHR_materials_transmission = 1, ior 1.5 -> the Glass arm of material/mod.rs:200-256)
+    between them, rows of desks with rounded chairs; Disney dielectric (metallic 0) materials with a seeded image
+    base colour everywhere else; lit only by the environment map through the windows, oriented like the glTF
+    importer's default light (pathtracer/importer/gltf.rs:553-562: Euler(-pi/2, 0, 0)).  detail = 1 gives about
+    600k triangles (BASELINE configs[3]: 1920x1080, 128 spp, depth 15)."""
+    from . import textures as tx
+    rng = np.random.default_rng(seed)
+    s = RenderScene()
+    t = np.linspace(0, 1, tex_size, endpoint=False)
+    xx, yy = np.meshgrid(t, t)
+    base = np.stack([0.6 + 0.3 * np.sin(2 * np.pi * (2 * xx + rng.uniform())), 0.55 + 0.3 * np.sin(2 * np.pi * (3 * yy + rng.uniform())),
+                     0.5 + 0.3 * np.sin(2 * np.pi * ((xx - yy) + rng.uniform()))], axis=-1)
+    planks = (((np.floor(yy * 24)) % 2) * 0.2 + 0.8)[..., None]
+    img8 = np.clip(255 * base * planks + rng.normal(0, 5, base.shape), 0, 255).astype(np.uint8)
+    col_tex = tx.spectrum_texture(s, img8)
+    wall = s.add_material(abi.MAT_DISNEY, [col_tex, s.const_f(0.0), s.const_f(1.5), s.const_f(0.8)])
+    wood = s.add_material(abi.MAT_DISNEY, [col_tex, s.const_f(0.0), s.const_f(1.5), s.const_f(0.45)])
+    plastic = s.add_material(abi.MAT_DISNEY, [s.const_rgb([0.2, 0.35, 0.7]), s.const_f(0.0), s.const_f(1.5), s.const_f(0.3)])
+    glass = s.add_material(abi.MAT_GLASS, [s.const_rgb([1, 1, 1]), s.const_rgb([1, 1, 1]), s.const_f(1.5)])
+    LX, LY, LZ = 9.0, 3.6, 6.0
+    d = max(float(detail), 0.02) * 1.9  # detail = 1 -> ~600k triangles
+    n = lambda k: max(1, int(round(k * math.sqrt(d))))
+    tris = 0
+
+    def plane(origin, eu, ev, normal):
+        o, eu, ev, nn = (np.array(v, np.float64) for v in (origin, eu, ev, normal))
+        return lambda u, v: (o + u[:, None] * eu + v[:, None] * ev, np.tile(nn, (len(u), 1)))
+
+    def box(lo, hi, material, nu, nv, nw, uv_scale=(1.0, 1.0)):
+        lo, hi = np.array(lo, np.float64), np.array(hi, np.float64)
+        e = hi - lo
+        k = 0
+        k += _surface(s, plane([lo[0], lo[1], hi[2]], [e[0], 0, 0], [0, e[1], 0], [0, 0, 1]), nu, nv, material, uv_scale)
+        k += _surface(s, plane([hi[0], lo[1], lo[2]], [-e[0], 0, 0], [0, e[1], 0], [0, 0, -1]), nu, nv, material, uv_scale)
+        k += _surface(s, plane([hi[0], lo[1], hi[2]], [0, 0, -e[2]], [0, e[1], 0], [1, 0, 0]), nw, nv, material, uv_scale)
+        k += _surface(s, plane([lo[0], lo[1], lo[2]], [0, 0, e[2]], [0, e[1], 0], [-1, 0, 0]), nw, nv, material, uv_scale)
+        k += _surface(s, plane([lo[0], hi[1], hi[2]], [e[0], 0, 0], [0, 0, -e[2]], [0, 1, 0]), nu, nw, material, uv_scale)
+        k += _surface(s, plane([lo[0], lo[1], lo[2]], [e[0], 0, 0], [0, 0, e[2]], [0, -1, 0]), nu, nw, material, uv_scale)
+        return k
+    tris += _surface(s, plane([-LX, 0, -LZ], [2 * LX, 0, 0], [0, 0, 2 * LZ], [0, 1, 0]), n(220), n(150), wood, (6, 4))
+    tris += _surface(s, plane([-LX, LY, LZ], [2 * LX, 0, 0], [0, 0, -2 * LZ], [0, -1, 0]), n(160), n(110), wall, (4, 3))
+    tris += _surface(s, plane([-LX, 0, -LZ], [0, 0, 2 * LZ], [0, LY, 0], [1, 0, 0]), n(120), n(40), wall, (3, 1))
+    tris += _surface(s, plane([LX, 0, LZ], [0, 0, -2 * LZ], [0, LY, 0], [-1, 0, 0]), n(120), n(40), wall, (3, 1))
+    tris += _surface(s, plane([LX, 0, -LZ], [-2 * LX, 0, 0], [0, LY, 0], [0, 0, 1]), n(180), n(40), wall, (4, 1))
+    # window wall at z = +LZ: sill, lintel, piers, and glass slabs in the openings
+    nwin = 6
+    tris += box([-LX, 0.0, LZ - 0.15], [LX, 0.9, LZ + 0.15], wall, n(120), n(8), n(2))
+    tris += box([-LX, 3.0, LZ - 0.15], [LX, LY, LZ + 0.15], wall, n(120), n(6), n(2))
+    edges = np.linspace(-LX, LX, nwin + 1)
+    for i in range(nwin + 1):
+        xc = edges[i]
+        tris += box([max(xc - 0.25, -LX), 0.9, LZ - 0.15], [min(xc + 0.25, LX), 3.0, LZ + 0.15], wall, n(4), n(20), n(2))
+    for i in range(nwin):
+        tris += box([edges[i] + 0.25, 0.9, LZ - 0.02], [edges[i + 1] - 0.25, 3.0, LZ + 0.02], glass, n(6), n(6), 1)
+    # desks and chairs
+    rows_, cols_ = 5, 6
+    for r_ in range(rows_):
+        for c_ in range(cols_):
+            x = -LX + 2.0 + c_ * (2 * LX - 4.0) / (cols_ - 1)
+            z = -LZ + 2.2 + r_ * (2 * LZ - 4.6) / (rows_ - 1)
+            tris += box([x - 0.6, 0.72, z - 0.35], [x + 0.6, 0.76, z + 0.35], wood, n(22), n(2), n(14), (1, 1))
+            for lx, lz in ((-0.55, -0.3), (0.55, -0.3), (-0.55, 0.3), (0.55, 0.3)):
+                tris += box([x + lx - 0.025, 0.0, z + lz - 0.025], [x + lx + 0.025, 0.72, z + lz + 0.025], plastic, n(2), n(12), n(2))
+
+            def seat(u, v, x=x, z=z):
+                th, ph = 2 * np.pi * u, np.pi * v
+                nn = np.stack([np.sin(ph) * np.cos(th), np.cos(ph), np.sin(ph) * np.sin(th)], axis=1)
+                rad = np.array([0.24, 0.05, 0.24])
+                g = nn / rad
+                return np.array([x, 0.45, z - 0.7]) + nn * rad, g / np.linalg.norm(g, axis=1, keepdims=True)
+            tris += _surface(s, seat, n(36), n(18), plastic)
+
+            def back(u, v, x=x, z=z):
+                th = (u - 0.5) * 1.2
+                p = np.stack([x + 0.3 * np.sin(th), 0.55 + 0.4 * v, z - 0.95 + 0.08 * (1 - np.cos(th))], axis=1)
+                nn = np.stack([-np.sin(th) * 0.3, np.zeros_like(th), np.ones_like(th)], axis=1)
+                return p, nn / np.linalg.norm(nn, axis=1, keepdims=True)
+            tris += _surface(s, back, n(30), n(20), plastic)
+    # a glass sphere on the teacher's desk and the desk itself
+    tris += box([-1.2, 0.0, -LZ + 0.6], [1.2, 0.8, -LZ + 1.4], wood, n(40), n(20), n(16))
+    pos, nrm, idx, uv = uv_sphere(max(8, n(60)), max(16, n(120)))
+    s.add_mesh((pos * np.float32(0.22) + np.array([0.5, 1.02, -LZ + 1.0], np.float32)).astype(np.float32), idx, glass, normal=nrm, uv=uv)
+    tris += len(idx)
+    cr, sr = math.cos(-math.pi / 2), math.sin(-math.pi / 2)
+    l2w = np.array([[1, 0, 0, 0], [0, cr, -sr, 0], [0, sr, cr, 0], [0, 0, 0, 1]], np.float32)
+    tx.add_infinite_light(s, synthetic_env_map_1k() if env is None else env, light_to_world=l2w)
+    cam = look_at_camera([-7.5, 1.7, -4.6], [3.0, 1.2, 3.5], [0, 1, 0], 60.0, resolution)
+    return cam, s

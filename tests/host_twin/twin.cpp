@@ -29,9 +29,9 @@ struct TwinScene {
 // traversal stack with the capacity the GPU kernel would get (16 / 32 / 64 LDS entries) and an
 // overflow flag, so that a stack misuse shows up on the CPU instead of corrupting LDS on the GPU
 struct CheckedStack {
-    uint32_t s[64]; int n = 0; int cap = 64; bool *overflow = nullptr;
-    void push(uint32_t v) { if (n >= cap) { if (overflow) *overflow = true; return; } s[n++] = v; }
-    uint32_t pop() { return s[--n]; }
+    uint32_t s[64]; float te[64]; int n = 0; int cap = 64; bool *overflow = nullptr;
+    void push(uint32_t v, float t) { if (n >= cap) { if (overflow) *overflow = true; return; } s[n] = v; te[n] = t; ++n; }
+    void pop(uint32_t &v, float &t) { --n; v = s[n]; t = te[n]; }
     bool empty() const { return n == 0; }
     void clear() { n = 0; }
 };
@@ -148,6 +148,7 @@ int twin_scene_create(const PtrsSceneDesc *d, void **out) {
     return PTRS_OK;
 }
 void twin_scene_destroy(void *s) { delete static_cast<TwinScene *>(s); }
+void twin_scene_info(void *s, uint32_t *max_depth, uint32_t *stack_bound, uint32_t *n_nodes2) { auto *t = static_cast<TwinScene *>(s); *max_depth = t->H.max_depth; *stack_bound = t->H.stack_bound; *n_nodes2 = (uint32_t)t->H.nodes2.size(); }
 
 int twin_render(void *sp, const PtrsCamera *cam, const PtrsRenderParams *prm, PtrsFilmPixel *film, float *sample_rgb, PtrsStats *stats) {
     if (!g_tables.ok) { g_err = "tables not loaded"; return PTRS_ERR_INVALID; }

@@ -131,6 +131,20 @@ def test_triangle_soup_matches_oracle(ptrs, orc, scenes):
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
 
 
+def test_stack_spill_path_matches_oracle(ptrs, orc, scenes, monkeypatch):
+    """PTRS_STACK_LDS=8 forces the 8-entry LDS stack column on a deep tree, so traversal spills the
+    excess entries to the global per-thread columns: results must not change."""
+    monkeypatch.setenv("PTRS_STACK_LDS", "8")
+    cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-4, 4, (20000, 3)); d = rng.normal(size=(20000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d, np.full((20000, 1), np.inf)], axis=1).astype(np.float32)
+    hg, _ = ptrs.trace_rays(scene, rays)
+    ho, _ = orc.OracleScene(scene).trace_rays(rays)
+    assert np.array_equal(hg["prim"], ho["prim"]) and np.array_equal(hg["t"].view(np.uint32), ho["t"].view(np.uint32))
+
+
 def test_full_size_properties(ptrs):
     """BASELINE configs[1] at full size (1024x1024, depth 15; 16 spp to stay within the test budget):
     size-independent properties -- filter-weight sums are the analytic constant in the interior,
@@ -163,6 +177,15 @@ def test_colonnade_matches_oracle(ptrs, orc, scenes):
     image texture, directional + point lights) at reduced resolution."""
     cam, scene = scenes.colonnade((160, 90))
     assert 240000 < scene.num_triangles() < 290000
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15)
+
+
+def test_classroom_matches_oracle(ptrs, orc, scenes):
+    """Classroom-class stand-in (BASELINE configs[3]: ~600k triangles, solid glass panes + a glass sphere,
+    Disney dielectrics with an image texture, lit only by a 512x1024 HDR environment map through the
+    windows) at reduced resolution: FEAT_FULL kernels on an HBM-resident tree."""
+    cam, scene = scenes.classroom((128, 72))
+    assert 560000 < scene.num_triangles() < 650000
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15)
 
 

@@ -87,3 +87,9 @@ def test_twin_textured_env(scenes, orc):
     light: the FEAT_FULL instantiations of the device code."""
     cam, scene = scenes.textured_env((72, 48))
     _compare(orc, cam, scene, 4, 15)
+
+
+def test_twin_classroom_small(scenes, orc):
+    """Reduced-detail classroom stand-in (glass slabs + sphere, Disney dielectrics, 512x1024 env map)."""
+    cam, scene = scenes.classroom((64, 36), detail=0.02)
+    _compare(orc, cam, scene, 2, 15)
