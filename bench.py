@@ -40,13 +40,36 @@ HBM_PEAK_GBS = 8000.0
 TRAFFIC_PMC_DEFAULT = (83.37e6 + 150.85e6 + 48.32e6 + 29.40e6) * 1024.0 / 192.0
 
 
+def host_cores():
+    """Cores this process may actually use: min(os.cpu_count, affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / per))))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(pkg, rows=128):
     """Oracle (CPU port of the reference path) on rows [500, 500+rows) of the same frame."""
     from oracle import orc
 
     cam, scene = pkg.import_scene(SCENE, (WIDTH, HEIGHT))
     o = orc.OracleScene(scene)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     p = orc.make_params(WIDTH, HEIGHT, SPP, DEPTH, row_begin=500, row_end=500 + rows)
     t = time.time()
     _, _, st = o.render(cam, p, n_threads=cores)
@@ -59,7 +82,7 @@ def cpu_baseline(pkg, rows=128):
     dt1 = time.time() - t
     rays1 = st1.rays_extension + st1.rays_shadow + st1.rays_mis
     return {
-        "value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port", "os_cpu_count": os.cpu_count(),
         "single_thread_mray_s": rays1 / dt1 / 1e6, "single_thread_sample": "rows 500..502, %d rays, %.1f s" % (rays1, dt1),
         "msample_per_s": st.samples / dt / 1e6,
         "sample": "output rows 500..%d of the 1024x1024/256spp/depth-15 Cornell frame (%d li() samples, %d rays, %.1f s, %d threads, 16x16 tiles, dynamic queue)"

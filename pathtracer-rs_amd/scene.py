@@ -14,6 +14,7 @@ reference also does once, outside PathIntegrator::render; the results cross the 
 arrays (include/ptrs.h).  All arithmetic is binary32 in the order nalgebra 0.32.2 performs it.
 """
 import math
+import os
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -307,8 +308,15 @@ def _bsdf_to_material(scene, el):
     raise ValueError("unsupported bsdf type " + str(kind))
 
 
-def import_scene(path, resolution):
-    """common/importer/mod.rs:6-25 for the .xml branch: returns (Camera, RenderScene)."""
+def import_scene(path, resolution, default_lights=False, env_map=None):
+    """common/importer/mod.rs:6-25: dispatch on the extension; returns (Camera, RenderScene).
+    .gltf / .glb -> gltf.import_gltf (default_lights = the CLI's --default_lights); .xml -> the Mitsuba subset."""
+    ext = os.path.splitext(str(path))[1].lower()
+    if ext in (".gltf", ".glb"):
+        from .gltf import import_gltf
+        return import_gltf(path, resolution, default_lights=default_lights, env_map=env_map)
+    if ext != ".xml":
+        raise ValueError("unsupported format!")
     root = ET.parse(path).getroot()
     sensor = root.find("sensor")
     fov = float(sensor.find("float[@name='fov']").get("value"))

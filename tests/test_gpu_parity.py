@@ -189,6 +189,14 @@ def test_classroom_matches_oracle(ptrs, orc, scenes):
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15)
 
 
+def test_imported_gltf_matches_oracle(ptrs, orc, tmp_path):
+    """The synthetic glTF asset (tests/gltf_fixture.py) imported by gltf.py: Disney + normal map + metallic-roughness
+    textures, glass, mirror, alpha-masked card, constant and textured emissive quads, directional + point lights."""
+    import gltf_fixture as gf
+    cam, scene = ptrs.import_scene(gf.write_gltf(str(tmp_path), glb=True), (96, 64))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
+
+
 def test_film_matches_twin_bitwise(ptrs, orc):
     """The film kernel (LDS-tiled gather) forms every pixel's sums in the same order as the host twin's
     film_item (sample index, then sample-pixel x, then y), so the accumulators agree bit for bit --
