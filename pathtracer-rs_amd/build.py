@@ -48,7 +48,7 @@ HEADLESS = os.path.join(HERE, "ptrs_headless")
 
 def build_host(force=False):
     """C++ host mirror + headless CLI (g++, links libptrs_hip.so with rpath $ORIGIN)."""
-    srcs = [os.path.join(HERE, "host", f) for f in ("headless.cpp", "ptrs_host.cpp")]
+    srcs = [os.path.join(HERE, "host", f) for f in ("headless.cpp", "ptrs_host.cpp", "ptrs_gltf.cpp")]
     deps = srcs + [os.path.join(HERE, "host", "ptrs_host.hpp"), LIB]
     if not force and os.path.exists(HEADLESS) and all(os.path.getmtime(HEADLESS) >= os.path.getmtime(d) for d in deps):
         return HEADLESS

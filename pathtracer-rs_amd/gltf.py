@@ -389,12 +389,16 @@ def default_camera(world_bound, resolution):
     """get_default_camera (common/importer/gltf.rs:68-85): eye at the bound's max corner looking at the origin,
     yfov = pi/2 * (height / width)."""
     lo, hi = world_bound
-    eye = np.array(hi, dtype=np.float64)
-    f = -eye / np.linalg.norm(eye)
-    s_ = np.cross(f, np.array([0.0, 1.0, 0.0]))
-    s_ /= np.linalg.norm(s_)
-    u = np.cross(s_, f)
-    rot = np.stack([s_, u, -f], axis=1).astype(np.float32)
+    eye = [float(v) for v in hi]  # binary64 scalars, explicit order (the C++ host does the same)
+    en = math.sqrt(eye[0] * eye[0] + eye[1] * eye[1] + eye[2] * eye[2])
+    f = [-eye[0] / en, -eye[1] / en, -eye[2] / en]
+    up = [0.0, 1.0, 0.0]
+    sv = [f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]]
+    sn = math.sqrt(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2])
+    sv = [x / sn for x in sv]
+    u = [sv[1] * f[2] - sv[2] * f[1], sv[2] * f[0] - sv[0] * f[2], sv[0] * f[1] - sv[1] * f[0]]
+    rot = np.array([[sv[k], u[k], -f[k]] for k in range(3)], dtype=np.float32)
+    eye = np.array(eye, dtype=np.float64)
     res = (F(resolution[0]), F(resolution[1]))
     return Camera(_quat_from_rotation_matrix(rot), eye.astype(np.float32), res[0] / res[1], F(math.pi / 2) * (res[1] / res[0]),
                   DEFAULT_Z_NEAR, DEFAULT_Z_FAR, resolution)

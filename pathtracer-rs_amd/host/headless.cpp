@@ -1,7 +1,7 @@
 // ptrs_headless -- the reference's headless front-end over the HIP backend.
 //
 // Mirrors src/main.rs:35-145 (flag subset: SCENE, -o/--output DIR, -s/--samples, -r/--resolution WxH,
-// -d/--max_depth, --headless; the viewer flags are accepted and ignored) and src/headless.rs:222-229
+// -d/--max_depth, --default_lights, --headless; the viewer flags are accepted and ignored) and src/headless.rs:222-229
 // (one-shot render, then film.to_rgba_image().save(DIR/render.png)).  Wiring follows main.rs:101-126:
 //   import -> SamplerBuilder::new(spp, film.get_sample_bounds()) -> PathIntegrator::new(.., max_depth)
 //   -> preprocess -> render -> save.
@@ -23,7 +23,8 @@ static bool parse_resolution(const char *s, int &w, int &h) { // main.rs:23-33
 }
 
 int main(int argc, char **argv) {
-    std::string scene_path, out_dir, dump_path;
+    std::string scene_path, out_dir, dump_path, dump_full_path, env_map_path;
+    bool default_lights = false;
     int spp = 1, max_depth = 15, w = 640, h = 480; // DEFAULT_RESOLUTION common/mod.rs:14
     bool have_out = false;
     for (int i = 1; i < argc; ++i) {
@@ -34,17 +35,21 @@ int main(int argc, char **argv) {
         else if (a == "-r" || a == "--resolution") { if (!parse_resolution(need("--resolution"), w, h)) { std::fprintf(stderr, "error: invalid resolution string\n"); return 2; } }
         else if (a == "-d" || a == "--max_depth") { const char *v = need("--max_depth"); char *e; long d = std::strtol(v, &e, 10); max_depth = (*e == 0) ? (int)d : 20; } // main.rs:21,87-97
         else if (a == "--dump-scene") dump_path = need("--dump-scene");
-        else if (a == "--headless" || a == "--default_lights") {}
+        else if (a == "--dump-scene-full") dump_full_path = need("--dump-scene-full");
+        else if (a == "--default_lights") default_lights = true; // main.rs:48,99
+        else if (a == "--env_map") env_map_path = need("--env_map"); // the Radiance .hdr --default_lights uses (the reference's bundled file is not shipped)
+        else if (a == "--headless") {}
         else if (a == "-c" || a == "--camera" || a == "-l" || a == "--log_level" || a == "-m" || a == "--module_log" || a == "--server") (void)need(a.c_str());
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "error: unknown flag %s\n", a.c_str()); return 2; }
         else scene_path = a;
     }
-    if (scene_path.empty() || (!have_out && dump_path.empty())) {
-        std::fprintf(stderr, "usage: ptrs_headless SCENE -o DIR [-s SPP] [-r WxH] [-d DEPTH] [--headless]\n");
+    if (scene_path.empty() || (!have_out && dump_path.empty() && dump_full_path.empty())) {
+        std::fprintf(stderr, "usage: ptrs_headless SCENE(.xml|.gltf|.glb) -o DIR [-s SPP] [-r WxH] [-d DEPTH] [--default_lights --env_map FILE.hdr] [--headless]\n");
         return 2;
     }
     Camera camera; RenderScene scene; std::string err;
-    if (!import_scene(scene_path, w, h, camera, scene, err)) { std::fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+    if (!import_scene(scene_path, w, h, camera, scene, err, default_lights, env_map_path)) { std::fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+    if (!dump_full_path.empty()) { if (!dump_scene_full(dump_full_path, camera, scene)) { std::fprintf(stderr, "error: cannot write %s\n", dump_full_path.c_str()); return 1; } if (!have_out && dump_path.empty()) return 0; }
     if (!dump_path.empty()) { if (!dump_scene(dump_path, camera, scene)) { std::fprintf(stderr, "error: cannot write %s\n", dump_path.c_str()); return 1; } if (!have_out) return 0; }
     int32_t sb[4];
     camera.film.get_sample_bounds(sb);

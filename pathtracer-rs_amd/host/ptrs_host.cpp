@@ -55,9 +55,9 @@ const PtrsSceneDesc &RenderScene::desc() {
     for (auto &m : meshes) {
         PtrsMesh a{};
         a.n_verts = (uint32_t)(m.pos.size() / 3); a.n_tris = (uint32_t)(m.indices.size() / 3);
-        a.pos = m.pos.data(); a.normal = m.normal.empty() ? nullptr : m.normal.data(); a.tangent = nullptr;
+        a.pos = m.pos.data(); a.normal = m.normal.empty() ? nullptr : m.normal.data(); a.tangent = m.tangent.empty() ? nullptr : m.tangent.data();
         a.uv = m.uv.empty() ? nullptr : m.uv.data(); a.indices = m.indices.data();
-        a.material = m.material; a.alpha_mask_tex = -1;
+        a.material = m.material; a.alpha_mask_tex = m.alpha_mask_tex;
         abi_meshes_.push_back(a);
     }
     desc_ = PtrsSceneDesc{};
@@ -265,10 +265,14 @@ static void make_camera(const float cam_to_world[16], float fov_deg, int film_w,
     else if (r[0][0] > r[1][1] && r[0][0] > r[2][2]) { float d = std::sqrt(((1.0f + r[0][0]) - r[1][1]) - r[2][2]) * 2.0f; w = (r[2][1] - r[1][2]) / d; i = q * d; j = (r[0][1] + r[1][0]) / d; k = (r[0][2] + r[2][0]) / d; }
     else if (r[1][1] > r[2][2]) { float d = std::sqrt(((1.0f + r[1][1]) - r[0][0]) - r[2][2]) * 2.0f; w = (r[0][2] - r[2][0]) / d; i = (r[0][1] + r[1][0]) / d; j = q * d; k = (r[1][2] + r[2][1]) / d; }
     else { float d = std::sqrt(((1.0f + r[2][2]) - r[0][0]) - r[1][1]) * 2.0f; w = (r[1][0] - r[0][1]) / d; i = (r[0][2] + r[2][0]) / d; j = (r[1][2] + r[2][1]) / d; k = q * d; }
+    const float rot[4] = {i, j, k, w}, trans[3] = {M[3], M[7], M[11]};
+    make_camera_perspective(rot, trans, (float)res_w / (float)res_h, fov * ((float)film_h / (float)film_w), 0.01f, 10000.0f, res_w, res_h, cam);
+}
+
+void make_camera_perspective(const float rot[4], const float trans[3], float aspect, float fovy, float zn, float zf, int res_w, int res_h, Camera &cam) {
     PtrsCamera &c = cam.abi;
-    c.rot[0] = i; c.rot[1] = j; c.rot[2] = k; c.rot[3] = w;
-    c.trans[0] = M[3]; c.trans[1] = M[7]; c.trans[2] = M[11];
-    const float W = (float)res_w, H = (float)res_h, aspect = W / H, fovy = fov * ((float)film_h / (float)film_w), zn = 0.01f, zf = 10000.0f;
+    std::memcpy(c.rot, rot, 16); std::memcpy(c.trans, trans, 12);
+    const float W = (float)res_w, H = (float)res_h;
     c.m11 = 1.0f / (float)std::tan((double)(fovy / 2.0f));
     c.m00 = c.m11 / aspect;
     c.m22 = (zf + zn) / (zn - zf);
@@ -284,9 +288,11 @@ static void make_camera(const float cam_to_world[16], float fov_deg, int film_w,
     cam.film = Film(res_w, res_h);
 }
 
-bool import_scene(const std::string &path, int res_w, int res_h, Camera &camera, RenderScene &scene, std::string &err) {
+bool import_scene(const std::string &path, int res_w, int res_h, Camera &camera, RenderScene &scene, std::string &err, bool default_lights, const std::string &env_map_path) {
     const size_t dot = path.rfind('.');
-    if (dot == std::string::npos || path.substr(dot) != ".xml") { err = "unsupported format!"; return false; } // importer/mod.rs:15-23 (.gltf: next round)
+    const std::string ext = dot == std::string::npos ? "" : path.substr(dot);
+    if (ext == ".gltf" || ext == ".glb") return import_gltf(path, res_w, res_h, default_lights, env_map_path, camera, scene, err); // importer/mod.rs:17-18
+    if (ext != ".xml") { err = "unsupported format!"; return false; } // importer/mod.rs:15-23
     std::ifstream f(path, std::ios::binary);
     if (!f) { err = "cannot open " + path; return false; }
     std::string src((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -373,6 +379,41 @@ bool dump_scene(const std::string &path, const Camera &cam, const RenderScene &s
     for (auto &t : s.textures) { w32((uint32_t)t.kind); w32((uint32_t)t.channels); std::fwrite(t.value, 4, 3, f); std::fwrite(t.value2, 4, 3, f); }
     w32((uint32_t)s.lights.size());
     for (auto &l : s.lights) { w32((uint32_t)l.kind); w32(l.mesh); w32(l.tri); w32((uint32_t)l.ke_tex); }
+    std::fclose(f);
+    return true;
+}
+
+bool dump_scene_full(const std::string &path, const Camera &cam, const RenderScene &s) {
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto w32 = [&](uint32_t v) { std::fwrite(&v, 4, 1, f); };
+    auto wf = [&](const float *p, size_t n) { if (n) std::fwrite(p, 4, n, f); };
+    std::fwrite("PTRSDMP2", 1, 8, f);
+    std::fwrite(&cam.abi, sizeof(PtrsCamera), 1, f);
+    w32((uint32_t)s.meshes.size());
+    for (auto &m : s.meshes) {
+        w32((uint32_t)(m.pos.size() / 3)); w32((uint32_t)(m.indices.size() / 3)); w32((uint32_t)m.material); w32((uint32_t)m.alpha_mask_tex);
+        w32((m.normal.empty() ? 0u : 1u) | (m.uv.empty() ? 0u : 2u) | (m.tangent.empty() ? 0u : 4u));
+        wf(m.pos.data(), m.pos.size()); wf(m.normal.data(), m.normal.size()); wf(m.uv.data(), m.uv.size()); wf(m.tangent.data(), m.tangent.size());
+        std::fwrite(m.indices.data(), 4, m.indices.size(), f);
+    }
+    w32((uint32_t)s.materials.size());
+    for (auto &m : s.materials) { w32((uint32_t)m.kind); for (int k = 0; k < 6; ++k) w32((uint32_t)m.tex[k]); w32((uint32_t)m.flags); w32((uint32_t)m.inner); }
+    w32((uint32_t)s.textures.size());
+    for (auto &t : s.textures) {
+        w32((uint32_t)t.kind); w32((uint32_t)t.channels); wf(t.value, 3); wf(t.value2, 3); wf(&t.su, 1); wf(&t.sv, 1); wf(&t.du, 1); wf(&t.dv, 1);
+        w32((uint32_t)t.wrap); w32((uint32_t)t.n_levels);
+        for (int l = 0; l < t.n_levels; ++l) { w32((uint32_t)t.level_cols[l]); w32((uint32_t)t.level_rows[l]); wf(t.level_data[l], (size_t)t.level_cols[l] * t.level_rows[l] * t.channels); }
+    }
+    w32((uint32_t)s.lights.size());
+    for (auto &l : s.lights) {
+        w32((uint32_t)l.kind); wf(l.v, 3); wf(l.c, 3); w32(l.mesh); w32(l.tri); w32((uint32_t)l.ke_tex); w32((uint32_t)l.lmap_tex);
+        wf(l.light_to_world, 16); wf(l.world_to_light, 16); w32((uint32_t)l.dist_nu); w32((uint32_t)l.dist_nv);
+        if (l.kind == PTRS_LIGHT_INFINITE) {
+            const size_t nu = (size_t)l.dist_nu, nv = (size_t)l.dist_nv;
+            wf(l.dist_func, nu * nv); wf(l.dist_cdf, (nu + 1) * nv); wf(l.dist_func_int, nv); wf(l.marg_cdf, nv + 1); wf(&l.marg_func_int, 1);
+        }
+    }
     std::fclose(f);
     return true;
 }

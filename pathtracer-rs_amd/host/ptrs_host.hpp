@@ -3,7 +3,8 @@
 // The reference is compiled code (Rust); no Rust toolchain exists in the build image, so the host
 // side above the C ABI (include/ptrs.h) is mirrored in C++ with the reference's names and
 // argument meaning:
-//   importer::import(path, resolution)                  src/common/importer/mod.rs:6-25 (.xml branch)
+//   importer::import(path, resolution, default_lights)  src/common/importer/mod.rs:6-25 (.xml and .gltf/.glb branches)
+//   from_gltf / RenderScene::from_gltf                  src/common/importer/gltf.rs, src/pathtracer/importer/gltf.rs (ptrs_gltf.cpp)
 //   Camera::new / get_camera                            src/common/mod.rs:33-62, importer/mitsuba.rs:685-710
 //   Film::{new, clear, get_sample_bounds, to_rgba_image} src/common/film.rs:132-251
 //   RenderScene::from_mitsuba                           src/pathtracer/importer/mitsuba.rs:84-428 (rgb-parameter subset)
@@ -13,6 +14,7 @@
 // produce bit-identical scene descriptions (tests/test_host_cpp.py).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -36,9 +38,24 @@ struct Camera {
 };
 
 struct Mesh {
-    std::vector<float> pos, normal, uv;
+    std::vector<float> pos, normal, uv, tangent;
     std::vector<uint32_t> indices;
     int32_t material = -1;
+    int32_t alpha_mask_tex = -1;
+};
+
+// MIP pyramid of an image texture (MIPMap::new, texture.rs:279-405), owned by the scene
+struct TexImage {
+    int channels = 0;
+    std::vector<std::vector<float>> levels; // level l: rows*cols*channels, row-major
+    std::vector<int32_t> cols, rows;
+    std::vector<const float *> ptrs;
+};
+// Distribution2D of an infinite light (sampling.rs:185-230)
+struct EnvDistribution {
+    int nu = 0, nv = 0;
+    std::vector<float> func, cdf, func_int, marg_cdf;
+    float marg_func_int = 0.0f;
 };
 
 struct RenderScene {
@@ -46,6 +63,8 @@ struct RenderScene {
     std::vector<PtrsMaterial> materials;
     std::vector<PtrsTexture> textures;
     std::vector<PtrsLight> lights;
+    std::vector<std::unique_ptr<TexImage>> images;          // referenced by textures[i].level_data
+    std::vector<std::unique_ptr<EnvDistribution>> env_dists; // referenced by lights[i].dist_*
     // flat description for ptrs_scene_create (valid while *this is alive and unmodified)
     const PtrsSceneDesc &desc();
     size_t num_triangles() const;
@@ -89,9 +108,17 @@ private:
 // importer::import for Mitsuba XML (rectangle / cube shapes, twosided / diffuse / conductor /
 // roughconductor / dielectric / plastic / roughplastic bsdfs with rgb parameters, area emitters,
 // perspective sensor).  Returns false and fills err on failure.
-bool import_scene(const std::string &path, int res_w, int res_h, Camera &camera, RenderScene &scene, std::string &err);
+bool import_scene(const std::string &path, int res_w, int res_h, Camera &camera, RenderScene &scene, std::string &err,
+                  bool default_lights = false, const std::string &env_map_path = "");
+// the .gltf / .glb branch (ptrs_gltf.cpp).  default_lights adds the environment light of `--default_lights`; the
+// reference reads data/abandoned_tank_farm_04_1k.hdr from its source tree, here the Radiance file is named by the caller.
+bool import_gltf(const std::string &path, int res_w, int res_h, bool default_lights, const std::string &env_map_path,
+                 Camera &camera, RenderScene &scene, std::string &err);
+// Camera::new (common/mod.rs:33-62) from an isometry (unit quaternion i,j,k,w + translation) and Perspective3::new arguments
+void make_camera_perspective(const float rot_ijkw[4], const float trans[3], float aspect, float fovy, float znear, float zfar, int res_w, int res_h, Camera &cam);
 
 bool write_png_rgba8(const std::string &path, int w, int h, const std::vector<uint8_t> &rgba, std::string &err);
 bool dump_scene(const std::string &path, const Camera &camera, const RenderScene &scene);
+bool dump_scene_full(const std::string &path, const Camera &camera, const RenderScene &scene); // every field of the flat description
 
 } // namespace ptrs_host

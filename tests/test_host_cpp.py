@@ -96,3 +96,166 @@ def test_headless_cli_renders_png(cli, ptrs, tmp_path):
     ref = np.clip(srgb * 255.0 + 0.5, 0, 255).astype(np.uint8)
     assert np.abs(png[..., :3].astype(int) - ref.astype(int)).max() <= 1
     assert (png[..., :3] != ref).mean() < 0.01
+
+
+# ---- glTF branch: the C++ importer (host/ptrs_gltf.cpp) against the Python importer (gltf.py), every field -------------
+def _read_full_dump(path, abi):
+    b = open(path, "rb").read()
+    assert b[:8] == b"PTRSDMP2"
+    st = {"off": 8 + C.sizeof(abi.PtrsCamera)}
+    cam = abi.PtrsCamera.from_buffer_copy(b[8:st["off"]])
+
+    def u32():
+        v = struct.unpack_from("<I", b, st["off"])[0]
+        st["off"] += 4
+        return v
+
+    def arr(dt, n):
+        a = np.frombuffer(b, dtype=dt, count=n, offset=st["off"])
+        st["off"] += a.nbytes
+        return a
+    meshes = []
+    for _ in range(u32()):
+        nv, nt, mat, alpha, fl = u32(), u32(), _i32(u32()), _i32(u32()), u32()
+        meshes.append(dict(pos=arr("<f4", nv * 3), normal=arr("<f4", nv * 3) if fl & 1 else None, uv=arr("<f4", nv * 2) if fl & 2 else None,
+                           tangent=arr("<f4", nv * 3) if fl & 4 else None, indices=arr("<u4", nt * 3), material=mat, alpha_mask_tex=alpha))
+    mats = [dict(kind=u32(), tex=[_i32(u32()) for _ in range(6)], flags=u32(), inner=_i32(u32())) for _ in range(u32())]
+    texs = []
+    for _ in range(u32()):
+        t = dict(kind=u32(), channels=u32(), value=arr("<f4", 3), value2=arr("<f4", 3), uvmap=arr("<f4", 4), wrap=u32())
+        t["levels"] = []
+        for _ in range(u32()):
+            cols, rows = u32(), u32()
+            t["levels"].append(arr("<f4", cols * rows * t["channels"]).reshape(rows, cols, t["channels"]))
+        texs.append(t)
+    lights = []
+    for _ in range(u32()):
+        l = dict(kind=u32(), v=arr("<f4", 3), c=arr("<f4", 3), mesh=u32(), tri=u32(), ke_tex=_i32(u32()), lmap_tex=_i32(u32()),
+                 light_to_world=arr("<f4", 16), world_to_light=arr("<f4", 16), nu=u32(), nv=u32())
+        if l["kind"] == abi.LIGHT_INFINITE:
+            nu, nv = l["nu"], l["nv"]
+            l.update(func=arr("<f4", nu * nv), cdf=arr("<f4", (nu + 1) * nv), func_int=arr("<f4", nv), marg_cdf=arr("<f4", nv + 1), marg_func_int=arr("<f4", 1)[0])
+        lights.append(l)
+    assert st["off"] == len(b)
+    return cam, meshes, mats, texs, lights
+
+
+def _bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(-1).view(np.uint32)
+
+
+def _compare_full(abi, dump, cam_p, scene):
+    cam_c, meshes, mats, texs, lights = dump
+    assert bytes(cam_c) == bytes(cam_p.to_abi())
+    assert len(meshes) == len(scene.meshes)
+    for c, m in zip(meshes, scene.meshes):
+        for k in ("pos", "normal", "uv", "tangent"):
+            assert (c[k] is None) == (m[k] is None), k
+            if c[k] is not None:
+                assert np.array_equal(_bits(c[k]), _bits(m[k])), k
+        assert np.array_equal(c["indices"], np.asarray(m["indices"], np.uint32).reshape(-1))
+        assert (c["material"], c["alpha_mask_tex"]) == (m["material"], m["alpha_mask_tex"])
+    assert [(m["kind"], m["tex"], m["inner"]) for m in mats] == [(m["kind"], (list(m["tex"]) + [-1] * 6)[:6], m["inner"]) for m in scene.materials]
+    assert len(texs) == len(scene.textures)
+    for c, t in zip(texs, scene.textures):
+        assert (c["kind"], c["channels"]) == (t["kind"], t["channels"])
+        if t["kind"] == abi.TEX_CONSTANT:
+            assert np.array_equal(_bits(c["value"][:t["channels"]]), _bits(np.broadcast_to(np.asarray(t["value"], np.float32), (3,))[:t["channels"]]))
+        else:
+            assert c["wrap"] == t["wrap"] and len(c["levels"]) == len(t["levels"])
+            for lc, lp in zip(c["levels"], t["levels"]):
+                assert lc.shape == np.asarray(lp).reshape(lc.shape).shape
+                # identical operation order; the only foreign arithmetic is pow(x, 2.4) of the sRGB decode (numpy vs libm)
+                assert np.allclose(lc, np.asarray(lp).reshape(lc.shape), rtol=3e-7, atol=0)
+    assert len(lights) == len(scene.lights)
+    for c, l in zip(lights, scene.lights):
+        assert c["kind"] == l["kind"]
+        if l["kind"] == abi.LIGHT_AREA:
+            assert (c["mesh"], c["tri"], c["ke_tex"]) == (l["mesh"], l["tri"], l["ke_tex"])
+        elif l["kind"] in (abi.LIGHT_POINT, abi.LIGHT_DIRECTIONAL):
+            assert np.array_equal(_bits(c["v"]), _bits(l["v"])) and np.array_equal(_bits(c["c"]), _bits(l["c"]))
+        else:
+            d = l["dist"]
+            assert c["lmap_tex"] == l["lmap_tex"] and (c["nu"], c["nv"]) == (d["nu"], d["nv"])
+            assert np.array_equal(_bits(c["light_to_world"]), _bits(l["light_to_world"]))
+            assert np.allclose(c["world_to_light"], np.asarray(l["world_to_light"]).reshape(-1), atol=1e-7)
+            for k in ("func", "cdf", "func_int", "marg_cdf"):
+                assert np.array_equal(_bits(c[k]), _bits(d[k])), k
+            assert np.float32(c["marg_func_int"]) == np.float32(d["marg_func_int"])
+
+
+def _write_rgbe(path, img):
+    """Flat (non-RLE) Radiance file from an (rows, cols, 3) float32 image."""
+    img = np.asarray(img, dtype=np.float32)
+    m = img.max(axis=-1)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0).astype(np.int32)
+    scale = np.where(m > 1e-32, np.exp2((8 - e).astype(np.float32)), 0).astype(np.float32)
+    rgbe = np.zeros(img.shape[:2] + (4,), np.uint8)
+    rgbe[..., :3] = np.clip(img * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % img.shape[:2])
+        f.write(rgbe.tobytes())
+
+
+@pytest.mark.parametrize("glb", [False, True])
+def test_cpp_gltf_import_matches_python_import(cli, ptrs, tmp_path, glb):
+    import gltf_fixture as gf
+    path = gf.write_gltf(str(tmp_path), glb=glb)
+    dump = str(tmp_path / "full.dump")
+    subprocess.check_call([cli, path, "--dump-scene-full", dump, "-r", "96x64"])
+    cam_p, scene = ptrs.import_scene(path, (96, 64))
+    _compare_full(ptrs.abi, _read_full_dump(dump, ptrs.abi), cam_p, scene)
+
+
+def test_cpp_gltf_default_camera_and_env_light(cli, ptrs, scenes, tmp_path):
+    import json
+    import gltf_fixture as gf
+    path = gf.write_gltf(str(tmp_path), glb=False)
+    doc = json.load(open(path))
+    for n in doc["nodes"]:
+        n.pop("camera", None)
+    nocam = str(tmp_path / "nocam.gltf")
+    json.dump(doc, open(nocam, "w"))
+    hdr = str(tmp_path / "env.hdr")
+    _write_rgbe(hdr, scenes.synthetic_env_map(16, 32))
+    dump = str(tmp_path / "full.dump")
+    subprocess.check_call([cli, nocam, "--dump-scene-full", dump, "-r", "80x40", "--default_lights", "--env_map", hdr])
+    cam_p, scene = ptrs.import_scene(nocam, (80, 40), default_lights=True, env_map=hdr)
+    _compare_full(ptrs.abi, _read_full_dump(dump, ptrs.abi), cam_p, scene)
+    r = subprocess.run([cli, nocam, "--dump-scene-full", dump, "--default_lights"], capture_output=True, text=True)
+    assert r.returncode == 1 and "env_map" in r.stderr
+
+
+def test_cpp_gltf_errors(cli, tmp_path):
+    import json
+    import gltf_fixture as gf
+    path = gf.write_gltf(str(tmp_path), glb=False)
+    doc = json.load(open(path))
+    doc["samplers"][0]["wrapT"] = 33071
+    bad = str(tmp_path / "bad.gltf")
+    json.dump(doc, open(bad, "w"))
+    r = subprocess.run([cli, bad, "--dump-scene-full", str(tmp_path / "x.dump")], capture_output=True, text=True)
+    assert r.returncode == 1 and "wrapS != wrapT" in r.stderr
+    open(bad, "w").write("{ \"asset\": ")
+    r = subprocess.run([cli, bad, "--dump-scene-full", str(tmp_path / "x.dump")], capture_output=True, text=True)
+    assert r.returncode == 1 and "JSON" in r.stderr
+
+
+@pytest.mark.gpu
+def test_headless_cli_renders_gltf(cli, ptrs, tmp_path):
+    """ptrs_headless zoo.glb ... == the Python host importing and rendering the same asset (films agree; 8-bit
+    output within one level)."""
+    from PIL import Image
+    import gltf_fixture as gf
+    path = gf.write_gltf(str(tmp_path), glb=True)
+    subprocess.check_call([cli, path, "-o", str(tmp_path), "-s", "8", "-r", "96x64", "-d", "6", "--headless"])
+    png = np.asarray(Image.open(str(tmp_path / "render.png")))
+    cam, scene = ptrs.import_scene(path, (96, 64))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(8, cam.film.get_sample_bounds()), 6)
+    integ.render(cam, scene)
+    img = cam.film.to_rgb().astype(np.float64)
+    srgb = np.where(img <= 0.0031308, 12.92 * img, 1.055 * np.power(np.maximum(img, 1e-12), 1 / 2.4) - 0.055)
+    ref = np.clip(srgb * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    assert png.shape == (64, 96, 4)
+    assert np.abs(png[..., :3].astype(int) - ref.astype(int)).max() <= 2 and (png[..., :3] != ref).mean() < 0.02
