@@ -39,13 +39,15 @@ PT_HD bool slab_test(const v4 &a, const v4 &b, f3 o, f3 inv, const bool neg[3], 
 // a 16-byte-vector copy [4 per pair node | 3 per triangle] -- on gfx950 the kernels stage small scenes
 // (Cornell: 29 pair nodes + 36 triangles = 3.6 KB) into LDS once per workgroup and walk them there.
 struct GeomGlobal {
-    const DNode2 *nodes2; const DTri *tris;
-    PT_MEM void node(uint32_t i, v4 &a, v4 &b, v4 &c, v4 &d) const { const v4 *q = reinterpret_cast<const v4 *>(nodes2 + i); a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
+    const v4 *nodesv; const DTri *tris; // nodesv: the scene's pair nodes (4 vectors each) or quad nodes (8 vectors each)
+    PT_MEM void node(uint32_t i, v4 &a, v4 &b, v4 &c, v4 &d) const { const v4 *q = nodesv + 4u * i; a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
+    PT_MEM void node8(uint32_t i, v4 *o) const { const v4 *q = nodesv + 8u * i; for (int k = 0; k < 8; ++k) o[k] = q[k]; }
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { const v4 *q = reinterpret_cast<const v4 *>(tris + k); a = q[0]; b = q[1]; c = q[2]; }
 };
 struct GeomLocal {
     const v4 *nodes4; const v4 *tris4;
     PT_MEM void node(uint32_t i, v4 &a, v4 &b, v4 &c, v4 &d) const { const v4 *q = nodes4 + 4u * i; a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
+    PT_MEM void node8(uint32_t i, v4 *o) const { const v4 *q = nodes4 + 8u * i; for (int k = 0; k < 8; ++k) o[k] = q[k]; }
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { a = tris4[3u * k]; b = tris4[3u * k + 1u]; c = tris4[3u * k + 2u]; }
 };
 
@@ -96,10 +98,10 @@ PT_HD bool alpha_rejects(const DScene &sc, uint32_t prim, int32_t alpha_tex, con
 //     coincident surfaces compete at (rounded-)equal t.
 // n_nodes counts child boxes tested, n_tris triangle tests.
 template <bool ANY, bool ALPHA, class Stack, class Geom>
-PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
     out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f; out.flags = 0;
     stack.clear(); // an any-hit query may have returned early and left entries behind
-    if (sc.n_nodes2 == 0) return false;
+    if (sc.n_nodes2 + sc.n_nodes4 == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
     uint32_t cur = 0; // reference to process next (interior index or leaf), REF_NONE when done
@@ -147,14 +149,111 @@ PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max,
     return hit;
 }
 
+
+// The leaf's triangles, in order (a later hit with equal t replaces the earlier one, Q14).  Returns true when an
+// any-hit query is done.
+template <bool ANY, bool ALPHA, class Geom>
+PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, f3 d, float &t_max, HitRec &out, bool &hit, uint32_t &n_tris) {
+    const uint32_t leaf_first = leaf & REF_FIRST_MASK, leaf_count = ((leaf >> REF_COUNT_SHIFT) & 15u) + 1u;
+    for (uint32_t i = 0; i < leaf_count; ++i) {
+        v4 ta, tb, tc;
+        G.tri(leaf_first + i, ta, tb, tc);
+        const f3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
+        const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
+        ++n_tris;
+        TriHit h;
+        if (tri_test(o, d, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
+            if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) continue;
+            if (ANY) { out.prim = 0; return true; }
+            hit = true; t_max = h.t;
+            out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
+        }
+    }
+    return false;
+}
+
+// Quad-node traversal (DNode4): one fetch covers two levels of the binary tree.  Slots are visited in the order the
+// binary traversal would reach them -- near child's (near, far) grandchildren, then the far child's -- and every
+// stacked slot carries its entry distance for the pop-time test.  Testing a grandchild's box directly is equivalent
+// to the reference's child-then-grandchild tests because boxes nest exactly (a union of floats is exact) and the slab
+// test is monotone in the box: a ray that passes a grandchild's test passes its parent's, with a smaller or equal
+// entry distance.
+template <bool ANY, bool ALPHA, class Stack, class Geom>
+PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+    out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f; out.flags = 0;
+    stack.clear(); // an any-hit query may have returned early and left entries behind
+    if (sc.n_nodes2 + sc.n_nodes4 == 0) return false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
+    uint32_t cur = 0;
+    bool hit = false;
+    while (cur != REF_NONE) {
+        while (cur != REF_NONE && !(cur & REF_LEAF)) {
+            v4 q[8];
+            G.node8(cur, q);
+            uint32_t r0 = f2u(q[6].x), r1 = f2u(q[6].y), r2 = f2u(q[6].z), r3 = f2u(q[6].w);
+            const uint32_t axes = f2u(q[7].x);
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+            bool h0 = r0 != REF_NONE && slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0) && t0 < t_max;
+            bool h1 = r1 != REF_NONE && slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1) && t1 < t_max;
+            bool h2 = r2 != REF_NONE && slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2) && t2 < t_max;
+            bool h3 = r3 != REF_NONE && slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3) && t3 < t_max;
+            n_nodes += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
+            const uint32_t ax = axes & 3u, aa = (axes >> 2) & 3u, ab = (axes >> 4) & 3u;
+            const bool sw = ax < 3u && neg[ax], swa = aa < 3u && neg[aa], swb = ab < 3u && neg[ab];
+            if (axes & 0x100u) { t0 = t1 = t2 = t3 = -3.402823466e38f; } // chunks of one leaf: no pop-time re-test
+#define PT_SWAP(c, ra, ta, ha, rb, tb, hb) { const uint32_t rr = c ? rb : ra; const float tt = c ? tb : ta; const bool hh = c ? hb : ha; rb = c ? ra : rb; tb = c ? ta : tb; hb = c ? ha : hb; ra = rr; ta = tt; ha = hh; }
+            PT_SWAP(swa, r0, t0, h0, r1, t1, h1)
+            PT_SWAP(swb, r2, t2, h2, r3, t3, h3)
+            PT_SWAP(sw, r0, t0, h0, r2, t2, h2)
+            PT_SWAP(sw, r1, t1, h1, r3, t3, h3)
+#undef PT_SWAP
+            // visiting order is now 0,1,2,3: the first hit is entered, later hits are stacked last-first
+            if (h3 && (h0 || h1 || h2)) stack.push(r3, t3);
+            if (h2 && (h0 || h1)) stack.push(r2, t2);
+            if (h1 && h0) stack.push(r1, t1);
+            if (h0) cur = r0; else if (h1) cur = r1; else if (h2) cur = r2; else if (h3) cur = r3;
+            else {
+                cur = REF_NONE;
+                while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
+            }
+        }
+        if (cur == REF_NONE) break;
+        if (leaf_test<ANY, ALPHA>(G, sc, cur, o, d, t_max, out, hit, n_tris)) return true;
+        cur = REF_NONE;
+        while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
+    }
+    return hit;
+}
+
+// QUAD selects the node form the geometry source holds (pair nodes: LDS-staged small scenes; quad nodes: the rest)
+template <bool QUAD, bool ANY, bool ALPHA, class Stack, class Geom>
+PT_HD bool bvh_trace_g(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+    if (QUAD) return bvh_trace_quad<ANY, ALPHA>(G, sc, o, d, t_max, stack, out, n_nodes, n_tris);
+    return bvh_trace_pair<ANY, ALPHA>(G, sc, o, d, t_max, stack, out, n_nodes, n_tris);
+}
+
+PT_HD GeomGlobal geom_global(const DScene &sc) {
+    GeomGlobal G; G.tris = sc.tris;
+    G.nodesv = sc.n_nodes4 ? reinterpret_cast<const v4 *>(sc.nodes4) : reinterpret_cast<const v4 *>(sc.nodes2);
+    return G;
+}
+
+// Traversal out of global memory in whichever node form the scene carries.
+template <bool ANY, bool ALPHA, class Stack>
+PT_HD bool bvh_trace_any_form(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
+    const GeomGlobal G = geom_global(sc);
+    if (sc.n_nodes4) return bvh_trace_quad<ANY, ALPHA>(G, sc, o, d, t_max, stack, out, n_nodes, n_tris);
+    return bvh_trace_pair<ANY, ALPHA>(G, sc, o, d, t_max, stack, out, n_nodes, n_tris);
+}
+
 template <bool ANY, class Stack>
 PT_HD bool bvh_trace(const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
-    GeomGlobal G; G.nodes2 = sc.nodes2; G.tris = sc.tris;
-    return bvh_trace_g<ANY, true>(G, sc, o, d, t_max, stack, out, n_nodes, n_tris);
+    return bvh_trace_any_form<ANY, true>(sc, o, d, t_max, stack, out, n_nodes, n_tris);
 }
 
 struct LocalStack { // host twin / small fixed uses
-    uint32_t s[64]; float te[64]; int n = 0;
+    uint32_t s[128]; float te[128]; int n = 0;
     PT_MEM void push(uint32_t v, float t) { s[n] = v; te[n] = t; ++n; }
     PT_MEM void pop(uint32_t &v, float &t) { --n; v = s[n]; t = te[n]; }
     PT_MEM bool empty() const { return n == 0; }

@@ -18,7 +18,9 @@
 namespace pt {
 
 struct HostScene {
-    std::vector<DNode2> nodes2; // traversal layout, derived from `nodes`
+    std::vector<DNode2> nodes2; // traversal layout, pair form (used when nodes + triangles fit the kernels' LDS staging area)
+    std::vector<DNode4> nodes4; // traversal layout, quad form (used otherwise); both derived from `nodes`
+    bool use_quad = false;
     std::vector<DNode> nodes;
     std::vector<DTri> tris;
     std::vector<DTriShade> shade;
@@ -277,6 +279,69 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
         H.max_depth = B.max_depth;
         for (auto &nd : H.nodes) if ((nd.meta & 0xffffu) == 0 && (nd.meta >> 16) > 2) return bad("internal: bad axis");
     }
+    uint32_t stack_bound2 = 0, stack_bound4 = 0;
+    // ---- quad nodes for traversal (pt_scene.h DNode4): two binary levels per record ----
+    if (!H.nodes.empty()) {
+        if (n_tris > REF_FIRST_MASK) return bad("too many triangles for the leaf reference encoding");
+        struct Conv {
+            const std::vector<DNode> &n; std::vector<DNode4> &out;
+            static void set_slot(DNode4 &d, int s, const DNode &nd, uint32_t ref) {
+                float *b = d.box + 6 * s;
+                b[0] = nd.pmin[0]; b[1] = nd.pmin[1]; b[2] = nd.pmin[2]; b[3] = nd.pmax0; b[4] = nd.pmax1; b[5] = nd.pmax2;
+                d.ref[s] = ref;
+            }
+            static DNode4 blank() { DNode4 d; std::memset(&d, 0, sizeof(d)); for (int s = 0; s < 4; ++s) d.ref[s] = REF_NONE; return d; }
+            // reference to a leaf range; ranges longer than REF_MAX_LEAF (only possible when many centroids coincide)
+            // become quad nodes whose slots are consecutive chunks sharing the leaf's box, visited in order and
+            // popped without the entry re-test (the reference tests such a leaf's box once)
+            uint32_t leaf_ref(const DNode &leaf, uint32_t first, uint32_t count) {
+                if (count <= REF_MAX_LEAF) return REF_LEAF | ((count - 1u) << REF_COUNT_SHIFT) | first;
+                const uint32_t me = (uint32_t)out.size();
+                out.push_back(blank());
+                DNode4 d = blank(); d.axes = 3u | (3u << 2) | (3u << 4) | 0x100u;
+                const uint32_t per = (count + 3u) / 4u;
+                uint32_t at = first, left = count;
+                for (int s = 0; s < 4 && left; ++s) { const uint32_t c = std::min(per, left); set_slot(d, s, leaf, leaf_ref(leaf, at, c)); at += c; left -= c; }
+                out[me] = d;
+                return me;
+            }
+            uint32_t ref_of(uint32_t i) { // reference for binary-tree node i
+                const DNode &nd = n[i];
+                const uint32_t np = nd.meta & 0xffffu;
+                if (np) return leaf_ref(nd, nd.offset, np);
+                const uint32_t me = (uint32_t)out.size();
+                out.push_back(blank());
+                DNode4 d = blank();
+                const uint32_t kid[2] = {i + 1, nd.offset};
+                uint32_t ax[2] = {3u, 3u};
+                for (int g = 0; g < 2; ++g) {
+                    const DNode &c = n[kid[g]];
+                    if (c.meta & 0xffffu) set_slot(d, 2 * g, c, leaf_ref(c, c.offset, c.meta & 0xffffu));
+                    else { ax[g] = (c.meta >> 16) & 0xffu; set_slot(d, 2 * g, n[kid[g] + 1], ref_of(kid[g] + 1)); set_slot(d, 2 * g + 1, n[c.offset], ref_of(c.offset)); }
+                }
+                d.axes = ((nd.meta >> 16) & 3u) | (ax[0] << 2) | (ax[1] << 4);
+                out[me] = d;
+                return me;
+            }
+        } conv{H.nodes, H.nodes4};
+        H.nodes4.reserve(H.nodes.size() / 3 + 2);
+        const uint32_t root = conv.ref_of(0);
+        if (root & REF_LEAF) { // the whole scene is one leaf: a node whose only slot is that leaf
+            DNode4 d = Conv::blank(); Conv::set_slot(d, 0, H.nodes[0], root); d.axes = 3u | (3u << 2) | (3u << 4);
+            H.nodes4.insert(H.nodes4.begin(), d);
+        }
+        // stack bound: at most three entries are stacked per level of the quad tree
+        std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 1u});
+        uint32_t depth4 = 0;
+        while (!st.empty()) {
+            auto [i, dp] = st.back(); st.pop_back();
+            depth4 = std::max(depth4, dp);
+            const DNode4 &nd = H.nodes4[i];
+            for (int s2 = 0; s2 < 4; ++s2) if (nd.ref[s2] != REF_NONE && !(nd.ref[s2] & REF_LEAF)) st.push_back({nd.ref[s2], dp + 1});
+        }
+        H.max_depth = std::max(H.max_depth, depth4 + 1);
+        stack_bound4 = 3u * depth4;
+    }
     // ---- pair nodes for traversal (pt_scene.h DNode2) ----
     if (!H.nodes.empty()) {
         struct Conv {
@@ -336,8 +401,12 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             if (nd.ref1 != REF_NONE && !(nd.ref1 & REF_LEAF)) st.push_back({nd.ref1, dp + 1});
         }
         H.max_depth = std::max(H.max_depth, depth2 + 1);
-        H.stack_bound = depth2;
+        stack_bound2 = depth2;
     }
+    // small scenes are walked out of LDS in pair form (cheaper steps when a fetch costs nothing), the rest in quad form
+    H.use_quad = 4u * H.nodes2.size() + 3u * n_tris > PAIR_FORM_MAX_V4;
+    if (const char *f = std::getenv("PTRS_NODE_FORM")) { if (!std::strcmp(f, "quad")) H.use_quad = true; else if (!std::strcmp(f, "pair")) H.use_quad = false; } // test hook
+    if (H.use_quad) { H.nodes2.clear(); H.stack_bound = stack_bound4; } else { H.nodes4.clear(); H.stack_bound = stack_bound2; }
     H.tris.resize(order.size());
     for (size_t k = 0; k < order.size(); ++k) {
         const DTriShade &T = H.shade[order[k]]; DTri &t = H.tris[k];

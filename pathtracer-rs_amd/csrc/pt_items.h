@@ -232,7 +232,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 // The two scene queries of estimate_direct and its use of their results: shadow any-hit
 // (integrator.rs:66-78, light.rs:38-42), MIS closest hit (119-134), then `l += beta * nLights * ld`
 // (444-446, 206-216).  One NEE record per call.
-template <int FEAT, class Stack, class Geom>
+template <int FEAT, bool QUAD, class Stack, class Geom>
 PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t pid, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
     const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
     const u4 n2 = P.nee2[pid];
@@ -241,7 +241,7 @@ PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32
     if (fl & NEE_SHADOW) {
         const v4 o = P.sh_o[pid], d = P.sh_d[pid];
         HitRec h;
-        if (!bvh_trace_g<true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris)) ld = ld + xyz(n0);
+        if (!bvh_trace_g<QUAD, true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris)) ld = ld + xyz(n0);
     }
     if (fl & NEE_MIS) {
         const DLight &Lt = sc.lights[li];
@@ -249,7 +249,7 @@ PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32
         const f3 wi = xyz(P.mis_d[pid]);
         HitRec h;
         f3 l2 = splat3(0.0f);
-        if (bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), wi, PT_INF, stack, h, n_nodes, n_tris)) {
+        if (bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), wi, PT_INF, stack, h, n_nodes, n_tris)) {
             const TriRegs T = load_tri_regs(sc.shade + h.prim);
             if (T.light == (int32_t)li) { // std::ptr::eq(light, isect_light) (Q11)
                 Surface s = tri_surface(T, h.prim, h.b0, h.b1, h.b2, -wi);

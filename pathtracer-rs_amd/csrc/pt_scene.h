@@ -30,6 +30,21 @@ struct alignas(16) DNode2 {
     uint32_t ref0, ref1, axis, pad;    // v3
 };
 static_assert(sizeof(DNode2) == 64, "node2");
+
+// Quad node: TWO levels of the binary tree in one 128-byte record (8 x 16 B = one L2 line).  Slots 0,1 are the
+// children of the node's first child A, slots 2,3 those of its second child B; when A (or B) is itself a leaf it
+// occupies slot 0 (or 2) and slot 1 (or 3) is REF_NONE.  Box s = floats [6s, 6s+6) = min xyz, max xyz.
+// axes: bits 0-1 split axis of the node, 2-3 of A, 4-5 of B (3 = never swap); bit 8: entries stacked from this node
+// are popped without the entry-distance re-test (chunks of one over-long leaf share the leaf's box).
+// Visiting [near group: near slot, far slot][far group: near slot, far slot] reproduces the binary traversal's
+// order (accelerator.rs:397-408) with half the dependent fetches.
+struct alignas(16) DNode4 {
+    float box[24];
+    uint32_t ref[4];
+    uint32_t axes, pad[3];
+};
+static_assert(sizeof(DNode4) == 128, "node4");
+enum : uint32_t { PAIR_FORM_MAX_V4 = 1024 }; // largest scene (4 vectors per pair node + 3 per triangle) the kernels stage into LDS
 enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0xffffffffu, REF_FIRST_MASK = 0x07ffffffu, REF_COUNT_SHIFT = 27, REF_MAX_LEAF = 16 };
 
 enum : uint32_t { TRI_HAS_NORMAL = 1, TRI_HAS_TANGENT = 2, TRI_REVERSE = 8, TRI_SWAPS = 16, TRI_DEGENERATE = 32, TRI_HAS_ALPHA = 64,
@@ -87,8 +102,9 @@ struct alignas(16) DLight {
 };
 
 struct DScene {
-    const DNode2 *nodes2;   // traversal nodes (pairs)
-    uint32_t n_nodes2, pad0;
+    const DNode2 *nodes2;   // traversal nodes, pair form: small scenes that the kernels stage into LDS
+    uint32_t n_nodes2, n_nodes4; // exactly one of the two forms is present
+    const DNode4 *nodes4;   // traversal nodes, quad form: everything else
     const DNode *nodes;     // the binary tree in the reference's 32-byte layout (kept for stats / export)
     const DTri *tris;
     const DTriShade *shade;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpi
     __shared__ uint2 lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
     __shared__ uint32_t lcount[8];
-    GeomLocal GL; GeomGlobal GG; GG.nodes2 = sc.nodes2; GG.tris = sc.tris;
+    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
     if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
     const uint32_t G = gridDim.x, b = blockIdx.x;
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpi
         const v4 o = P.ray_o[pid], d = P.ray_d[pid];
         LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
         HitRec h;
-        if (GEOM > 0) bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
-        else bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+        if (GEOM > 0) bvh_trace_g<false, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt); // pair nodes in LDS
+        else bvh_trace_g<true, false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);           // quad nodes through L1/L2
         u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
         P.hit[pid] = r;
         const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
@@ -232,7 +232,7 @@ template <int FEAT, int DEPTH, bool OVF, int GEOM>
 __global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
     __shared__ uint2 lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
-    GeomLocal GL; GeomGlobal GG; GG.nodes2 = sc.nodes2; GG.tris = sc.tris;
+    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom);
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, StackSp
     uint32_t nn = 0, nt = 0;
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
         LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-        if (GEOM > 0) connect_item<FEAT>(sc, GL, P, queue[i], stk, nn, nt);
-        else connect_item<FEAT>(sc, GG, P, queue[i], stk, nn, nt);
+        if (GEOM > 0) connect_item<FEAT, false>(sc, GL, P, queue[i], stk, nn, nt);
+        else connect_item<FEAT, true>(sc, GG, P, queue[i], stk, nn, nt);
     }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
@@ -380,7 +380,7 @@ struct PtrsScene {
     int device = 0;
     HostScene H; // host copy kept for validation / stats
     DScene sc{};
-    DevBuf nodes2, nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
+    DevBuf nodes2, nodes4, nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
     DevBuf stack_spill;  // global part of the traversal stacks (trees deeper than the LDS column), one column per resident thread
     StackSpill spill{nullptr, 0};
     uint32_t stack_lds = 16; // LDS stack entries per lane: 8 when the tree allows it, else 16 (+ spill)
@@ -390,7 +390,7 @@ struct PtrsScene {
     std::vector<hipEvent_t> ev_pool;
     int n_cu = 256;
     ~PtrsScene() {
-        for (auto &b : {&stack_spill, &nodes2, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
+        for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
         for (auto &b : ws) b.release();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
@@ -428,7 +428,7 @@ struct HipBackend {
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
         grid_max = ps->n_cu * 8;
-        geom4 = getenv("PTRS_NO_LDS_GEOM") ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims;
+        geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
         void **slots16[] = {(void **)&P.ray_o, (void **)&P.ray_d, (void **)&P.beta, (void **)&P.L, (void **)&P.st, (void **)&P.hit, (void **)&P.pfilm, (void **)&P.nee0,
@@ -578,11 +578,11 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ps->n_cu = prop.multiProcessorCount;
     HostScene &H = ps->H;
-    if ((rc = upload(ps->nodes2, H.nodes2)) || (rc = upload(ps->nodes, H.nodes)) || (rc = upload(ps->tris, H.tris)) || (rc = upload(ps->shade, H.shade)) || (rc = upload(ps->mats, H.mats)) ||
+    if ((rc = upload(ps->nodes2, H.nodes2)) || (rc = upload(ps->nodes4, H.nodes4)) || (rc = upload(ps->nodes, H.nodes)) || (rc = upload(ps->tris, H.tris)) || (rc = upload(ps->shade, H.shade)) || (rc = upload(ps->mats, H.mats)) ||
         (rc = upload(ps->texs, H.texs)) || (rc = upload(ps->levels, H.levels)) || (rc = upload(ps->texdata, H.texdata)) || (rc = upload(ps->lights, H.lights)) ||
         (rc = upload(ps->distdata, H.distdata)) || (rc = upload(ps->inf, H.inf_lights))) { delete ps; return rc; }
     DScene &sc = ps->sc;
-    sc.nodes2 = (const DNode2 *)ps->nodes2.p; sc.n_nodes2 = (uint32_t)H.nodes2.size(); sc.pad0 = 0;
+    sc.nodes2 = (const DNode2 *)ps->nodes2.p; sc.n_nodes2 = (uint32_t)H.nodes2.size(); sc.nodes4 = (const DNode4 *)ps->nodes4.p; sc.n_nodes4 = (uint32_t)H.nodes4.size();
     sc.nodes = (const DNode *)ps->nodes.p; sc.tris = (const DTri *)ps->tris.p; sc.shade = (const DTriShade *)ps->shade.p; sc.mats = (const DMaterial *)ps->mats.p;
     sc.texs = (const DTexture *)ps->texs.p; sc.levels = (const DTexLevel *)ps->levels.p; sc.texdata = (const float *)ps->texdata.p; sc.lights = (const DLight *)ps->lights.p;
     sc.distdata = (const float *)ps->distdata.p; sc.inf_lights = (const uint32_t *)ps->inf.p;
@@ -591,7 +591,7 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     // reached), else 16; what a deeper tree can stack beyond that spills to a global column per resident thread.  PTRS_STACK_LDS=8 forces the small
     // LDS column (with spill) on any scene -- a test hook for the spill path.
     const char *force = getenv("PTRS_STACK_LDS");
-    ps->stack_lds = (H.stack_bound <= 12 || (force && atoi(force) == 8)) ? 8u : 16u;
+    ps->stack_lds = (!H.use_quad || H.stack_bound <= 12 || (force && atoi(force) == 8)) ? 8u : 16u; // pair form (LDS-staged scenes) only exists with the 8-entry column
     if (H.stack_bound > ps->stack_lds) {
         const size_t threads = (size_t)ps->n_cu * 8 * BLOCK;
         if ((rc = ps->stack_spill.ensure(threads * (size_t)(H.stack_bound - ps->stack_lds) * sizeof(uint2))) != PTRS_OK) { delete ps; return rc; }

@@ -29,7 +29,7 @@ struct TwinScene {
 // traversal stack with the capacity the GPU kernel would get (16 / 32 / 64 LDS entries) and an
 // overflow flag, so that a stack misuse shows up on the CPU instead of corrupting LDS on the GPU
 struct CheckedStack {
-    uint32_t s[64]; float te[64]; int n = 0; int cap = 64; bool *overflow = nullptr;
+    uint32_t s[128]; float te[128]; int n = 0; int cap = 128; bool *overflow = nullptr;
     void push(uint32_t v, float t) { if (n >= cap) { if (overflow) *overflow = true; return; } s[n] = v; te[n] = t; ++n; }
     void pop(uint32_t &v, float &t) { --n; v = s[n]; t = te[n]; }
     bool empty() const { return n == 0; }
@@ -37,7 +37,7 @@ struct CheckedStack {
 };
 
 struct HostBackend {
-    bool overflow = false; int stack_cap = 64;
+    bool overflow = false; int stack_cap = 128;
     CheckedStack make_stack() { CheckedStack k; k.cap = stack_cap; k.overflow = &overflow; return k; }
     DScene sc; DSampler S; DCamera C; DParams R; DPaths P; DQueues Q;
     std::vector<std::vector<unsigned char>> pool;
@@ -55,7 +55,7 @@ struct HostBackend {
 
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t, int feat_, int feat_trace_, std::string &) {
         feat_trace = g_force_full ? FEAT_FULL : feat_trace_;
-        stack_cap = bvh_depth <= 16 ? 16 : (bvh_depth <= 32 ? 32 : 64);
+        (void)bvh_depth;
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; feat = g_force_full ? FEAT_FULL : feat_;
         gaussian_filter_table(table);
         P.ray_o = alloc<v4>(cap); P.ray_d = alloc<v4>(cap); P.beta = alloc<v4>(cap); P.L = alloc<v4>(cap); P.st = alloc<u4>(cap); P.hit = alloc<u4>(cap);
@@ -79,7 +79,7 @@ struct HostBackend {
             const uint32_t pid = q[i];
             const v4 o = P.ray_o[pid], d = P.ray_d[pid];
             CheckedStack stk = make_stack(); HitRec h; uint32_t nn = 0, nt = 0;
-            { GeomGlobal GX; GX.nodes2 = sc.nodes2; GX.tris = sc.tris; bvh_trace_g<false, (FEAT & FEAT_ALPHA) != 0>(GX, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt); }
+            bvh_trace_any_form<false, (FEAT & FEAT_ALPHA) != 0>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
             nodes += nn; tris += nt;
             u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
             const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
@@ -102,8 +102,9 @@ struct HostBackend {
     void connect(uint32_t it) {
         for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) {
             CheckedStack stk = make_stack(); uint32_t nn = 0, nt = 0;
-            GeomGlobal G; G.nodes2 = sc.nodes2; G.tris = sc.tris;
-            if (feat_trace == FEAT_FULL) connect_item<FEAT_FULL>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE>(sc, G, P, Q.nee[i], stk, nn, nt);
+            const GeomGlobal G = geom_global(sc);
+            if (sc.n_nodes4) { if (feat_trace == FEAT_FULL) connect_item<FEAT_FULL, true>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, true>(sc, G, P, Q.nee[i], stk, nn, nt); }
+            else { if (feat_trace == FEAT_FULL) connect_item<FEAT_FULL, false>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, false>(sc, G, P, Q.nee[i], stk, nn, nt); }
             nodes += nn; tris += nt;
         }
     }
@@ -140,7 +141,7 @@ int twin_scene_create(const PtrsSceneDesc *d, void **out) {
     int rc = build_host_scene(*d, s->H, g_err);
     if (rc != PTRS_OK) { delete s; return rc; }
     HostScene &H = s->H; DScene &sc = s->sc;
-    sc.nodes2 = H.nodes2.data(); sc.n_nodes2 = (uint32_t)H.nodes2.size(); sc.pad0 = 0;
+    sc.nodes2 = H.nodes2.data(); sc.n_nodes2 = (uint32_t)H.nodes2.size(); sc.nodes4 = H.nodes4.data(); sc.n_nodes4 = (uint32_t)H.nodes4.size();
     sc.nodes = H.nodes.data(); sc.tris = H.tris.data(); sc.shade = H.shade.data(); sc.mats = H.mats.data(); sc.texs = H.texs.data();
     sc.levels = H.levels.data(); sc.texdata = H.texdata.data(); sc.lights = H.lights.data(); sc.distdata = H.distdata.data(); sc.inf_lights = H.inf_lights.data();
     sc.n_nodes = (uint32_t)H.nodes.size(); sc.n_prims = (uint32_t)H.tris.size(); sc.n_lights = (uint32_t)H.lights.size(); sc.n_inf = (uint32_t)H.inf_lights.size();
@@ -148,12 +149,13 @@ int twin_scene_create(const PtrsSceneDesc *d, void **out) {
     return PTRS_OK;
 }
 void twin_scene_destroy(void *s) { delete static_cast<TwinScene *>(s); }
-void twin_scene_info(void *s, uint32_t *max_depth, uint32_t *stack_bound, uint32_t *n_nodes2) { auto *t = static_cast<TwinScene *>(s); *max_depth = t->H.max_depth; *stack_bound = t->H.stack_bound; *n_nodes2 = (uint32_t)t->H.nodes2.size(); }
+void twin_scene_info(void *s, uint32_t *max_depth, uint32_t *stack_bound, uint32_t *n_nodes2) { auto *t = static_cast<TwinScene *>(s); *max_depth = t->H.max_depth; *stack_bound = t->H.stack_bound; *n_nodes2 = (uint32_t)(t->H.nodes2.size() + t->H.nodes4.size()); }
 
 int twin_render(void *sp, const PtrsCamera *cam, const PtrsRenderParams *prm, PtrsFilmPixel *film, float *sample_rgb, PtrsStats *stats) {
     if (!g_tables.ok) { g_err = "tables not loaded"; return PTRS_ERR_INVALID; }
     TwinScene *s = static_cast<TwinScene *>(sp);
     HostBackend be;
+    be.stack_cap = (int)std::min<uint32_t>(s->H.stack_bound, 128u); // exactly the host's bound: the GPU sizes LDS + spill from it
     int rc = render_impl(be, s->sc, s->H, s->H.max_depth, *cam, *prm, reinterpret_cast<v4 *>(film), sample_rgb, stats, g_err);
     if (rc == PTRS_OK && be.overflow) { g_err = "traversal stack overflow (would corrupt LDS on the GPU)"; return PTRS_ERR_INVALID; }
     return rc;
