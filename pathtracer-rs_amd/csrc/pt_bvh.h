@@ -55,23 +55,25 @@ struct GeomLocal {
 // that does not depend on ray.t_max (the per-axis interval tests and `t_max_box > 0`) is decided here
 // and the entry distance returned; the caller finishes the test with `t_entry < ray.t_max`.
 PT_HD bool slab_entry6(float minx, float miny, float minz, float maxx, float maxy, float maxz, f3 o, f3 inv, const bool neg[3], float &t_entry) {
+    // straight-line form of the early-out code (same comparisons in the same order, so the same answer also when a
+    // product is NaN): 64 lanes rarely agree on which interval test fails, and a branch per test costs more than it saves
     const float k = 1.0f + 2.0f * gamma_err(3);
     float t_min = ((neg[0] ? maxx : minx) - o.x) * inv.x;
     float t_mx = ((neg[0] ? minx : maxx) - o.x) * inv.x;
-    float ty_min = ((neg[1] ? maxy : miny) - o.y) * inv.y;
+    const float ty_min = ((neg[1] ? maxy : miny) - o.y) * inv.y;
     float ty_max = ((neg[1] ? miny : maxy) - o.y) * inv.y;
     t_mx *= k; ty_max *= k;
-    if (t_min > ty_max || ty_min > t_mx) return false;
-    if (ty_min > t_min) t_min = ty_min;
-    if (ty_max < t_mx) t_mx = ty_max;
-    float tz_min = ((neg[2] ? maxz : minz) - o.z) * inv.z;
+    const bool miss_y = (t_min > ty_max) | (ty_min > t_mx);
+    t_min = ty_min > t_min ? ty_min : t_min;
+    t_mx = ty_max < t_mx ? ty_max : t_mx;
+    const float tz_min = ((neg[2] ? maxz : minz) - o.z) * inv.z;
     float tz_max = ((neg[2] ? minz : maxz) - o.z) * inv.z;
     tz_max *= k;
-    if (t_min > tz_max || tz_min > t_mx) return false;
-    if (tz_min > t_min) t_min = tz_min;
-    if (tz_max < t_mx) t_mx = tz_max;
+    const bool miss_z = (t_min > tz_max) | (tz_min > t_mx);
+    t_min = tz_min > t_min ? tz_min : t_min;
+    t_mx = tz_max < t_mx ? tz_max : t_mx;
     t_entry = t_min;
-    return t_mx > 0.0f;
+    return !(miss_y | miss_z) & (t_mx > 0.0f);
 }
 
 // Alpha-mask test of an accepted candidate (shape.rs:227-244 / 470-521): the mask texture is looked up at
@@ -114,8 +116,8 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
             const uint32_t ref0 = f2u(e.x), ref1 = f2u(e.y), axis = f2u(e.z);
             n_nodes += 2;
             float t0 = 0.0f, t1 = 0.0f;
-            const bool h0 = slab_entry6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t0) && t0 < t_max;
-            const bool h1 = ref1 != REF_NONE && slab_entry6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t1) && t1 < t_max;
+            const bool h0 = slab_entry6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t0) & (t0 < t_max);
+            const bool h1 = (ref1 != REF_NONE) & slab_entry6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t1) & (t1 < t_max);
             const bool second_first = axis < 3u && neg[axis];
             const uint32_t near_ref = second_first ? ref1 : ref0, far_ref = second_first ? ref0 : ref1;
             const bool near_hit = second_first ? h1 : h0, far_hit = second_first ? h0 : h1;
@@ -194,10 +196,10 @@ PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
             uint32_t r0 = f2u(q[6].x), r1 = f2u(q[6].y), r2 = f2u(q[6].z), r3 = f2u(q[6].w);
             const uint32_t axes = f2u(q[7].x);
             float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-            bool h0 = r0 != REF_NONE && slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0) && t0 < t_max;
-            bool h1 = r1 != REF_NONE && slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1) && t1 < t_max;
-            bool h2 = r2 != REF_NONE && slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2) && t2 < t_max;
-            bool h3 = r3 != REF_NONE && slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3) && t3 < t_max;
+            bool h0 = (r0 != REF_NONE) & slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0); h0 = h0 & (t0 < t_max);
+            bool h1 = (r1 != REF_NONE) & slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1); h1 = h1 & (t1 < t_max);
+            bool h2 = (r2 != REF_NONE) & slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2); h2 = h2 & (t2 < t_max);
+            bool h3 = (r3 != REF_NONE) & slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3); h3 = h3 & (t3 < t_max);
             n_nodes += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
             const uint32_t ax = axes & 3u, aa = (axes >> 2) & 3u, ab = (axes >> 4) & 3u;
             const bool sw = ax < 3u && neg[ax], swa = aa < 3u && neg[aa], swb = ab < 3u && neg[ab];

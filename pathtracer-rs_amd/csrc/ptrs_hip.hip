@@ -78,21 +78,22 @@ __device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uin
 // Traversal stack: column `threadIdx.x` of a [D][BLOCK] LDS array of (ref, entry distance) records.
 // OVF: entries beyond D go to this thread's column of a global array (StackSpill), so deep trees keep
 // the LDS footprint -- and with it the occupancy -- of a 16-entry stack.
-struct StackSpill { uint2 *p; uint32_t stride; };
+struct StackSpill { unsigned long long *p; uint32_t stride; };
 template <int D, bool OVF>
-struct LdsStack {
-    uint2 *col; uint2 *ovf; uint32_t ovf_stride;
+struct LdsStack { // records are packed into one 64-bit word (ref | entry distance << 32): one ds_write_b64 / ds_read_b64 each
+    unsigned long long *col, *ovf; uint32_t ovf_stride;
     int n;
-    __device__ inline void init(uint2 *lds, const StackSpill &sp) { col = lds + threadIdx.x; ovf = OVF ? sp.p + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr; ovf_stride = sp.stride; n = 0; }
+    __device__ inline void init(unsigned long long *lds, const StackSpill &sp) { col = lds + threadIdx.x; ovf = OVF ? sp.p + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr; ovf_stride = sp.stride; n = 0; }
     __device__ inline void push(uint32_t v, float t) {
-        uint2 e; e.x = v; e.y = f2u(t);
+        const unsigned long long e = (unsigned long long)v | ((unsigned long long)f2u(t) << 32);
         if (!OVF || n < D) col[n * BLOCK] = e; else ovf[(size_t)(n - D) * ovf_stride] = e;
         ++n;
     }
     __device__ inline void pop(uint32_t &v, float &t) {
         --n;
-        const uint2 e = (!OVF || n < D) ? col[n * BLOCK] : ovf[(size_t)(n - D) * ovf_stride];
-        v = e.x; t = u2f(e.y);
+        unsigned long long e = col[(OVF && n >= D ? D - 1 : n) * BLOCK]; // always an LDS read (no generic-address select); the spill is the rare path
+        if (OVF && n >= D) e = *(volatile unsigned long long *)(ovf + (size_t)(n - D) * ovf_stride); // volatile: keeps the compiler from folding both reads into one generic-address load
+        v = (uint32_t)e; t = u2f((uint32_t)(e >> 32));
     }
     __device__ inline bool empty() const { return n == 0; }
     __device__ inline void clear() { n = 0; }
@@ -122,7 +123,7 @@ template <bool ANY, int DEPTH, bool OVF>
 __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, StackSpill spill, const uint32_t *__restrict__ queue, const uint32_t *__restrict__ count,
                                                  const v4 *__restrict__ ro, const v4 *__restrict__ rd, u4 *__restrict__ hits,
                                                  uint32_t *__restrict__ occl, float *__restrict__ tout, unsigned long long *stats, uint32_t counters_on) {
-    __shared__ uint2 lds_stack[DEPTH * BLOCK];
+    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     const uint32_t n = *count;
     const uint32_t stride = gridDim.x * BLOCK;
     uint32_t nn = 0, nt = 0;
@@ -156,7 +157,7 @@ __device__ inline GeomLocal stage_geometry(const DScene &sc, v4 *lds) {
 
 template <int FEAT, int DEPTH, bool OVF, int GEOM>
 __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
-    __shared__ uint2 lds_stack[DEPTH * BLOCK];
+    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
     __shared__ uint32_t lcount[8];
     GeomLocal GL; const GeomGlobal GG = geom_global(sc);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(BLOCK, PTRS_SHADE_WAVES) void k_shade(DParams R, DS
 // Shadow (any-hit) and MIS (closest-hit) queries of the pending NEE records, resolved into L.
 template <int FEAT, int DEPTH, bool OVF, int GEOM>
 __global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
-    __shared__ uint2 lds_stack[DEPTH * BLOCK];
+    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
     GeomLocal GL; const GeomGlobal GG = geom_global(sc);
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom);
@@ -594,8 +595,8 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     ps->stack_lds = (!H.use_quad || H.stack_bound <= 12 || (force && atoi(force) == 8)) ? 8u : 16u; // pair form (LDS-staged scenes) only exists with the 8-entry column
     if (H.stack_bound > ps->stack_lds) {
         const size_t threads = (size_t)ps->n_cu * 8 * BLOCK;
-        if ((rc = ps->stack_spill.ensure(threads * (size_t)(H.stack_bound - ps->stack_lds) * sizeof(uint2))) != PTRS_OK) { delete ps; return rc; }
-        ps->spill.p = (uint2 *)ps->stack_spill.p; ps->spill.stride = (uint32_t)threads;
+        if ((rc = ps->stack_spill.ensure(threads * (size_t)(H.stack_bound - ps->stack_lds) * sizeof(unsigned long long))) != PTRS_OK) { delete ps; return rc; }
+        ps->spill.p = (unsigned long long *)ps->stack_spill.p; ps->spill.stride = (uint32_t)threads;
     }
     *out = ps;
     return PTRS_OK;
