@@ -106,6 +106,7 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     if (sc.n_nodes2 + sc.n_nodes4 == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
+    const RayShear shear = ray_shear(d);
     uint32_t cur = 0; // reference to process next (interior index or leaf), REF_NONE when done
     bool hit = false;
     while (cur != REF_NONE) {
@@ -138,7 +139,7 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
             const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
             ++n_tris;
             TriHit h;
-            if (tri_test(o, d, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
+            if (tri_test_s(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
                 if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) continue;
                 if (ANY) { out.prim = 0; return true; }
                 hit = true; t_max = h.t;
@@ -155,7 +156,7 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
 // The leaf's triangles, in order (a later hit with equal t replaces the earlier one, Q14).  Returns true when an
 // any-hit query is done.
 template <bool ANY, bool ALPHA, class Geom>
-PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, f3 d, float &t_max, HitRec &out, bool &hit, uint32_t &n_tris) {
+PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, const RayShear &shear, float &t_max, HitRec &out, bool &hit, uint32_t &n_tris) {
     const uint32_t leaf_first = leaf & REF_FIRST_MASK, leaf_count = ((leaf >> REF_COUNT_SHIFT) & 15u) + 1u;
     for (uint32_t i = 0; i < leaf_count; ++i) {
         v4 ta, tb, tc;
@@ -164,7 +165,7 @@ PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, f3 d,
         const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
         ++n_tris;
         TriHit h;
-        if (tri_test(o, d, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
+        if (tri_test_s(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
             if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) continue;
             if (ANY) { out.prim = 0; return true; }
             hit = true; t_max = h.t;
@@ -187,6 +188,7 @@ PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     if (sc.n_nodes2 + sc.n_nodes4 == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
+    const RayShear shear = ray_shear(d);
     uint32_t cur = 0;
     bool hit = false;
     while (cur != REF_NONE) {
@@ -221,7 +223,7 @@ PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
             }
         }
         if (cur == REF_NONE) break;
-        if (leaf_test<ANY, ALPHA>(G, sc, cur, o, d, t_max, out, hit, n_tris)) return true;
+        if (leaf_test<ANY, ALPHA>(G, sc, cur, o, shear, t_max, out, hit, n_tris)) return true;
         cur = REF_NONE;
         while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
     }

@@ -16,17 +16,30 @@ namespace pt {
 
 struct TriHit { float t, b0, b1, b2; };
 
-// returns true and fills h when the ray (o, d, t_max) hits triangle (p0,p1,p2) -- shape.rs:85-185
-PT_HD bool tri_test(f3 o, f3 d, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
+// The per-ray part of Triangle::intersect (shape.rs:92-109): the permutation that makes |d| largest in z and the
+// shear that aligns d with +z.  It depends on the ray only, so traversal computes it once instead of once per triangle
+// (three IEEE divisions each time).
+struct RayShear { int kz; float sx, sy, sz; };
+PT_HD RayShear ray_shear(f3 d) {
+    RayShear S;
+    S.kz = max_dimension(abs3(d));
+    int kx = S.kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    const float dx = comp(d, kx), dy = comp(d, ky), dz = comp(d, S.kz);
+    S.sx = -dx / dz; S.sy = -dy / dz; S.sz = 1.0f / dz;
+    return S;
+}
+
+// returns true and fills h when the ray (o, shear of d, t_max) hits triangle (p0,p1,p2) -- shape.rs:85-185
+PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
     f3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
-    int kz = max_dimension(abs3(d));
+    const int kz = S.kz;
     int kx = kz + 1; if (kx == 3) kx = 0;
     int ky = kx + 1; if (ky == 3) ky = 0;
-    f3 dp = mk3(comp(d, kx), comp(d, ky), comp(d, kz));
     p0t = mk3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
     p1t = mk3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
     p2t = mk3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
-    float sx = -dp.x / dp.z, sy = -dp.y / dp.z, sz = 1.0f / dp.z;
+    const float sx = S.sx, sy = S.sy, sz = S.sz;
     p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
     p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
     p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
@@ -38,13 +51,13 @@ PT_HD bool tri_test(f3 o, f3 d, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
         e1 = (float)((double)p0t.y * (double)p2t.x - (double)p0t.x * (double)p2t.y);
         e2 = (float)((double)p1t.y * (double)p0t.x - (double)p1t.x * (double)p0t.y);
     }
-    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
-    float det = e0 + e1 + e2;
-    if (det == 0.0f) return false;
+    const float det = e0 + e1 + e2;
+    // the common rejection (edge signs disagree) and the degenerate case in one test
+    if ((((e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f)) & ((e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f))) | (det == 0.0f)) return false;
     p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
-    float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-    if (det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) return false;
-    if (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)) return false;
+    const float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    const float lim = t_max * det;
+    if (((det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < lim))) | ((det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > lim)))) return false;
     float inv_det = 1.0f / det;
     float t = t_scaled * inv_det;
     // conservative t > delta_t test, shape.rs:163-185
@@ -61,6 +74,7 @@ PT_HD bool tri_test(f3 o, f3 d, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
     h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
     return true;
 }
+PT_HD bool tri_test(f3 o, f3 d, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) { return tri_test_s(o, ray_shear(d), t_max, p0, p1, p2, h); }
 
 // triangle partial derivatives, shape.rs:187-215.  Returns false for a degenerate triangle.
 PT_HD bool tri_dpduv(f3 p0, f3 p1, f3 p2, f2 uv0, f2 uv1, f2 uv2, f3 &dpdu, f3 &dpdv) {

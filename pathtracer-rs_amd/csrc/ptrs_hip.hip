@@ -194,11 +194,12 @@ __device__ inline void wave_count(uint32_t *counter, bool pred) {
 }
 
 // One instantiation per material kind (and feature set): lobe kinds are compile-time constants.
-#ifndef PTRS_SHADE_WAVES
-#define PTRS_SHADE_WAVES 1
-#endif
+// Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X: the Matte / FEAT_SIMPLE kernel (175
+// VGPRs unconstrained -> 2 waves) gains 9 % at 3 waves (168 VGPRs, no scratch growth); the FEAT_FULL kernels (up to 256
+// VGPRs) lose 5 % to spills when pressed to 3 and every kernel loses at 4.
+template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT == FEAT_SIMPLE) ? 3 : 1 }; };
 template <int MAT, int FEAT>
-__global__ __launch_bounds__(BLOCK, PTRS_SHADE_WAVES) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
+__global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
     __shared__ uint32_t lcount[4]; // next, nee, shadow rays, mis rays
     if (threadIdx.x < 4) lcount[threadIdx.x] = 0;
     __syncthreads();
