@@ -175,6 +175,45 @@ PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, const
     return false;
 }
 
+template <bool ANY, class Stack>
+PT_HD uint32_t pop_next_ref(Stack &stack, float t_max) {
+    while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) return r; }
+    return REF_NONE;
+}
+
+// One quad-node visit: tests the node's slots, stacks the postponed ones and returns the next reference in `cur`
+// (an inner node, a leaf, or REF_NONE when the stack has run dry).
+template <bool ANY, class Stack, class Geom>
+PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes) {
+    v4 q[8];
+    G.node8(cur, q);
+    uint32_t r0 = f2u(q[6].x), r1 = f2u(q[6].y), r2 = f2u(q[6].z), r3 = f2u(q[6].w);
+    const uint32_t axes = f2u(q[7].x);
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    bool h0 = (r0 != REF_NONE) & slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0); h0 = h0 & (t0 < t_max);
+    bool h1 = (r1 != REF_NONE) & slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1); h1 = h1 & (t1 < t_max);
+    bool h2 = (r2 != REF_NONE) & slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2); h2 = h2 & (t2 < t_max);
+    bool h3 = (r3 != REF_NONE) & slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3); h3 = h3 & (t3 < t_max);
+    n_nodes += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
+    const uint32_t ax = axes & 3u, aa = (axes >> 2) & 3u, ab = (axes >> 4) & 3u;
+    const bool sw = ax < 3u && neg[ax], swa = aa < 3u && neg[aa], swb = ab < 3u && neg[ab];
+    if (axes & 0x100u) { t0 = t1 = t2 = t3 = -3.402823466e38f; } // chunks of one leaf: no pop-time re-test
+#define PT_SWAP(c, ra, ta, ha, rb, tb, hb) { const uint32_t rr = c ? rb : ra; const float tt = c ? tb : ta; const bool hh = c ? hb : ha; rb = c ? ra : rb; tb = c ? ta : tb; hb = c ? ha : hb; ra = rr; ta = tt; ha = hh; }
+    PT_SWAP(swa, r0, t0, h0, r1, t1, h1)
+    PT_SWAP(swb, r2, t2, h2, r3, t3, h3)
+    PT_SWAP(sw, r0, t0, h0, r2, t2, h2)
+    PT_SWAP(sw, r1, t1, h1, r3, t3, h3)
+#undef PT_SWAP
+    // visiting order is now 0,1,2,3: the first hit is entered, later hits are stacked last-first
+    if (h3 && (h0 || h1 || h2)) stack.push(r3, t3);
+    if (h2 && (h0 || h1)) stack.push(r2, t2);
+    if (h1 && h0) stack.push(r1, t1);
+    if (h0) cur = r0; else if (h1) cur = r1; else if (h2) cur = r2; else if (h3) cur = r3;
+    else {
+        cur = pop_next_ref<ANY>(stack, t_max);
+    }
+}
+
 // Quad-node traversal (DNode4): one fetch covers two levels of the binary tree.  Slots are visited in the order the
 // binary traversal would reach them -- near child's (near, far) grandchildren, then the far child's -- and every
 // stacked slot carries its entry distance for the pop-time test.  Testing a grandchild's box directly is equivalent
@@ -192,36 +231,7 @@ PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     uint32_t cur = 0;
     bool hit = false;
     while (cur != REF_NONE) {
-        while (cur != REF_NONE && !(cur & REF_LEAF)) {
-            v4 q[8];
-            G.node8(cur, q);
-            uint32_t r0 = f2u(q[6].x), r1 = f2u(q[6].y), r2 = f2u(q[6].z), r3 = f2u(q[6].w);
-            const uint32_t axes = f2u(q[7].x);
-            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-            bool h0 = (r0 != REF_NONE) & slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0); h0 = h0 & (t0 < t_max);
-            bool h1 = (r1 != REF_NONE) & slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1); h1 = h1 & (t1 < t_max);
-            bool h2 = (r2 != REF_NONE) & slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2); h2 = h2 & (t2 < t_max);
-            bool h3 = (r3 != REF_NONE) & slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3); h3 = h3 & (t3 < t_max);
-            n_nodes += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
-            const uint32_t ax = axes & 3u, aa = (axes >> 2) & 3u, ab = (axes >> 4) & 3u;
-            const bool sw = ax < 3u && neg[ax], swa = aa < 3u && neg[aa], swb = ab < 3u && neg[ab];
-            if (axes & 0x100u) { t0 = t1 = t2 = t3 = -3.402823466e38f; } // chunks of one leaf: no pop-time re-test
-#define PT_SWAP(c, ra, ta, ha, rb, tb, hb) { const uint32_t rr = c ? rb : ra; const float tt = c ? tb : ta; const bool hh = c ? hb : ha; rb = c ? ra : rb; tb = c ? ta : tb; hb = c ? ha : hb; ra = rr; ta = tt; ha = hh; }
-            PT_SWAP(swa, r0, t0, h0, r1, t1, h1)
-            PT_SWAP(swb, r2, t2, h2, r3, t3, h3)
-            PT_SWAP(sw, r0, t0, h0, r2, t2, h2)
-            PT_SWAP(sw, r1, t1, h1, r3, t3, h3)
-#undef PT_SWAP
-            // visiting order is now 0,1,2,3: the first hit is entered, later hits are stacked last-first
-            if (h3 && (h0 || h1 || h2)) stack.push(r3, t3);
-            if (h2 && (h0 || h1)) stack.push(r2, t2);
-            if (h1 && h0) stack.push(r1, t1);
-            if (h0) cur = r0; else if (h1) cur = r1; else if (h2) cur = r2; else if (h3) cur = r3;
-            else {
-                cur = REF_NONE;
-                while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
-            }
-        }
+        while (cur != REF_NONE && !(cur & REF_LEAF)) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes);
         if (cur == REF_NONE) break;
         if (leaf_test<ANY, ALPHA>(G, sc, cur, o, shear, t_max, out, hit, n_tris)) return true;
         cur = REF_NONE;

@@ -188,6 +188,100 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpi
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
 
+// ---- lane-refill variant of the extension trace (quad-node scenes) --------------------------------------------------
+// A wave of k_extend runs as long as its longest ray while finished lanes idle: on a 262 k-triangle scene only 21 % of
+// the VALU lanes are active (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).  Here a lane that finishes its ray stores the hit
+// and, once at least `thresh` lanes of the wave are idle, takes the next ray of the workgroup's queue segment from an
+// LDS cursor.  The per-path epilogue (emission, environment, material bucketing) would run with a handful of lanes each
+// time, so it moves to k_epilogue, which walks the same segment with full waves afterwards.
+template <int FEAT, int DEPTH, bool OVF>
+__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
+    __shared__ uint32_t cursor;
+    const GeomGlobal G = geom_global(sc);
+    if (threadIdx.x == 0) cursor = 0;
+    __syncthreads();
+    const uint32_t Gn = gridDim.x, b = blockIdx.x;
+    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_EXT, Gn, b);
+    LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
+    uint32_t nn = 0, nt = 0;
+    uint32_t pid = 0, cur = REF_NONE;
+    bool has = false, dry = n == 0; // has: the lane holds an unfinished ray; dry: the segment has no rays left for this wave
+    f3 o = mk3(0, 0, 0), inv = mk3(1, 1, 1);
+    bool neg[3] = {false, false, false};
+    RayShear shear; shear.kz = 2; shear.sx = shear.sy = 0.0f; shear.sz = 1.0f;
+    float t_max = 0.0f; bool hit = false;
+    HitRec h; h.prim = -1; h.t = 0.0f; h.b0 = h.b1 = h.b2 = 0.0f; h.flags = 0;
+    for (;;) {
+        if (has && cur == REF_NONE) { // retire: the hit record is all that leaves this kernel
+            u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
+            P.hit[pid] = r;
+            has = false;
+        }
+        const unsigned long long idle = __ballot(!has);
+        if (!dry && (uint32_t)__popcll(idle) >= thresh) {
+            if (!has) {
+                const int lane = (int)__lane_id();
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&cursor, (uint32_t)__popcll(idle));
+                base = (uint32_t)__shfl((int)base, leader);
+                const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    pid = queue[i];
+                    const v4 ov = P.ray_o[pid], dv = P.ray_d[pid];
+                    o = xyz(ov); const f3 d = xyz(dv); t_max = ov.w;
+                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    neg[0] = inv.x < 0.0f; neg[1] = inv.y < 0.0f; neg[2] = inv.z < 0.0f;
+                    shear = ray_shear(d);
+                    h.prim = -1; h.t = t_max; h.b0 = h.b1 = h.b2 = 0.0f; h.flags = 0; hit = false;
+                    stk.clear(); cur = 0; has = true;
+                } else dry = true;
+            }
+            // lanes that still hold rays learn that the segment is exhausted from the cursor
+            if (cursor >= n) dry = true;
+        }
+        if (!__any(has)) break; // every ray of the segment this wave could get is retired
+        while (cur != REF_NONE && !(cur & REF_LEAF)) quad_visit<false>(G, cur, o, inv, neg, t_max, stk, nn);
+        if (cur != REF_NONE) {
+            leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(G, sc, cur, o, shear, t_max, h, hit, nt);
+            cur = pop_next_ref<false>(stk, t_max);
+        }
+    }
+    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
+}
+
+// The epilogue k_extend_rf leaves out: emission / environment / depth cut (integrator.rs:418-431) and material bucketing,
+// one full wave per 64 queue entries.
+template <int FEAT>
+__global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
+    __shared__ uint32_t lcount[8];
+    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_EXT, G, b);
+    for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        int k = -1; uint32_t pid = 0;
+        if (i < n) {
+            pid = queue[i];
+            const u4 r = P.hit[pid];
+            HitRec h; h.prim = (int32_t)r.x; h.t = 0.0f; h.b0 = u2f(r.y); h.b1 = u2f(r.z); h.b2 = u2f(r.w);
+            h.flags = h.prim >= 0 ? sc.shade[h.prim].flags : 0u; // same flags word as the leaf record's
+            k = extension_epilogue<FEAT>(R, sc, P, pid, h);
+        }
+        for (int m = 0; m < 6; ++m) {
+            if (!(kinds_mask & (1u << m))) continue;
+            const uint32_t slot = block_push(&lcount[m], k == m);
+            if (k == m) Q.mat[m][(size_t)b * seg_cap + slot] = pid;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && (kinds_mask & (1u << threadIdx.x))) *seg_count(Q, it, Q_MAT0 + (int)threadIdx.x, G, b) = lcount[threadIdx.x];
+}
+
 __device__ inline void wave_count(uint32_t *counter, bool pred) {
     const unsigned long long m = __ballot(pred);
     if (m != 0ull && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(counter, (uint32_t)__popcll(m));
@@ -408,6 +502,7 @@ struct HipBackend {
     uint32_t geom4 = 0xffffffffu; // 16-byte vectors needed to hold nodes + triangles in LDS
     uint32_t G = 1, seg_cap = 0;  // segmented queues of the current pass
     int grid_max = 2048;
+    uint32_t refill = 16; // idle-lane threshold of k_extend_rf (quad-node scenes); 0 = the fused k_extend everywhere (PTRS_REFILL)
     int rc = PTRS_OK;
     // timing
     struct Span { int cat; hipEvent_t a, b; };
@@ -430,6 +525,7 @@ struct HipBackend {
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
         grid_max = ps->n_cu * 8;
+        if (const char *e = getenv("PTRS_REFILL")) { int v = atoi(e); refill = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
@@ -465,6 +561,12 @@ struct HipBackend {
         dim3 g(G), b(BLOCK);
         const StackSpill sp = ps->spill;
         const bool ovf = sp.p != nullptr;
+        if (refill && sc.n_nodes4) {
+            if (ps->stack_lds == 8) { if (ovf) hipLaunchKernelGGL((k_extend_rf<FEAT, 8, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, 8, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); }
+            else { if (ovf) hipLaunchKernelGGL((k_extend_rf<FEAT, 16, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, 16, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); }
+            hipLaunchKernelGGL((k_epilogue<FEAT>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
+            return;
+        }
 #define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_extend<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, kinds_mask, seg_cap)
         if (ps->stack_lds == 8) {
             if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }

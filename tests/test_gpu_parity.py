@@ -145,6 +145,16 @@ def test_stack_spill_path_matches_oracle(ptrs, orc, scenes, monkeypatch):
     assert np.array_equal(hg["prim"], ho["prim"]) and np.array_equal(hg["t"].view(np.uint32), ho["t"].view(np.uint32))
 
 
+def test_fused_extension_kernel_on_a_large_scene(ptrs, orc, scenes, monkeypatch):
+    """PTRS_REFILL=0 selects the fused k_extend (traversal + epilogue in one kernel) instead of the lane-refill
+    kernel + k_epilogue that quad-node scenes use by default: same samples."""
+    monkeypatch.setenv("PTRS_REFILL", "0")
+    cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    monkeypatch.setenv("PTRS_REFILL", "1")
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+
+
 def test_full_size_properties(ptrs):
     """BASELINE configs[1] at full size (1024x1024, depth 15; 16 spp to stay within the test budget):
     size-independent properties -- filter-weight sums are the analytic constant in the interior,
