@@ -196,6 +196,17 @@ def main():
     cst = step(pkg.abi.FLAG_COUNTERS)
     c_rays = cst.rays
     nodes_per_ray, tris_per_ray = cst.nodes_visited / max(c_rays, 1), cst.tris_tested / max(c_rays, 1)
+    # untimed: one frame on a single pipeline lane, so that no two kernels share the machine -- the traversal kernels'
+    # own duration (the timed steps below overlap passes on several lanes, which stretches every kernel's span)
+    lanes_env = os.environ.get("PTRS_LANES")
+    os.environ["PTRS_LANES"] = "1"
+    xst = step(pkg.abi.FLAG_TIMING)
+    sync()
+    if lanes_env is None:
+        del os.environ["PTRS_LANES"]
+    else:
+        os.environ["PTRS_LANES"] = lanes_env
+    x_ms_trace, x_launches, x_rays = xst.ms_trace, xst.trace_launches, xst.rays
     for _ in range(args.warmup):
         step(pkg.abi.FLAG_TIMING)
     sync()
@@ -246,6 +257,9 @@ def main():
                          "kernel": "k_extend + k_connect (BVH closest-hit / any-hit traversal; bytes and time summed over both)", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                          "avg_launch_ms": float(vals[3]) / max(float(vals[6]), 1.0), "launches": int(float(vals[6])),
                          # path-state traffic of the wavefront design, reported apart from the traversal figure
+                         "timing": "HIP events around every traversal launch inside the timed steps; passes overlap on %s pipeline lanes there, so a launch's span includes time it shared the GPU with the other lanes' kernels" % (os.environ.get("PTRS_LANES") or "3"),
+                         "exclusive": {"what": "the same kernels in one untimed frame on a single lane (nothing overlapped)", "achieved": (x_rays * b_ray) / (x_ms_trace * 1e-3) / 1e9 if x_ms_trace > 0 else 0.0,
+                                       "frac": ((x_rays * b_ray) / (x_ms_trace * 1e-3) / 1e9 / HBM_PEAK_GBS) if x_ms_trace > 0 else 0.0, "avg_launch_ms": x_ms_trace / max(x_launches, 1)},
                          "b_state_bytes_per_path_round": 224, "hbm_copy_measured_gbs": hbm_copy_gbs(torch, dev)},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cornell":

@@ -472,6 +472,7 @@ int get_sobol(int device, SobolDevice **out) {
 
 } // namespace
 
+enum { MAX_LANES = 4 };
 struct PtrsScene {
     int device = 0;
     HostScene H; // host copy kept for validation / stats
@@ -479,15 +480,23 @@ struct PtrsScene {
     DevBuf nodes2, nodes4, nodes, tris, shade, mats, texs, levels, texdata, lights, distdata, inf;
     DevBuf stack_spill;  // global part of the traversal stacks (trees deeper than the LDS column), one column per resident thread
     StackSpill spill{nullptr, 0};
+    size_t spill_lane_elems = 0;
     uint32_t stack_lds = 16; // LDS stack entries per lane: 8 when the tree allows it, else 16 (+ spill)
     // render workspace, grown on demand and reused across calls
-    DevBuf ws[32];
-    DevBuf counts, totals, stats, table, film_tmp, samples_tmp;
+    DevBuf ws[MAX_LANES][32];   // per pipeline lane
+    DevBuf counts[MAX_LANES], totals[MAX_LANES];
+    DevBuf stats, table, film_tmp, samples_tmp;
+    hipStream_t lane_stream[MAX_LANES] = {}; // lane 0 runs on the caller's stream, the others on these
+    hipEvent_t lane_ev[MAX_LANES] = {};      // film-done per lane
     std::vector<hipEvent_t> ev_pool;
     int n_cu = 256;
     ~PtrsScene() {
-        for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &counts, &totals, &stats, &table, &film_tmp, &samples_tmp}) b->release();
-        for (auto &b : ws) b.release();
+        for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &stats, &table, &film_tmp, &samples_tmp}) b->release();
+        for (auto &b : counts) b.release();
+        for (auto &b : totals) b.release();
+        for (auto &l : ws) for (auto &b : l) b.release();
+        for (auto st : lane_stream) if (st) (void)hipStreamDestroy(st);
+        for (auto e : lane_ev) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
 };
@@ -501,6 +510,16 @@ struct HipBackend {
     int feat = FEAT_FULL, feat_trace = FEAT_FULL;
     uint32_t geom4 = 0xffffffffu; // 16-byte vectors needed to hold nodes + triangles in LDS
     uint32_t G = 1, seg_cap = 0;  // segmented queues of the current pass
+    // pipeline lanes: the members above (stream, R, P, Q, G, seg_cap) are those of the selected lane
+    struct Lane { hipStream_t stream; DParams R; DPaths P; DQueues Q; uint32_t G, seg_cap; };
+    Lane lane_[MAX_LANES]; uint32_t n_lanes = 3, cur = 0; // measured on Cornell: 1 lane 5376, 2: 6395, 3: 6578, 4: 6618 Mray/s
+    hipEvent_t film_prev = nullptr;
+    uint32_t lanes() { if (const char *e = getenv("PTRS_LANES")) { int v = atoi(e); n_lanes = (uint32_t)(v < 1 ? 1 : (v > MAX_LANES ? MAX_LANES : v)); } return n_lanes; } // called before begin()
+    void select(uint32_t l) {
+        if (l == cur) return;
+        lane_[cur] = Lane{stream, R, P, Q, G, seg_cap};
+        cur = l; stream = lane_[l].stream; R = lane_[l].R; P = lane_[l].P; Q = lane_[l].Q; G = lane_[l].G; seg_cap = lane_[l].seg_cap;
+    }
     int grid_max = 2048;
     uint32_t refill = 16; // idle-lane threshold of k_extend_rf (quad-node scenes); 0 = the fused k_extend everywhere (PTRS_REFILL)
     int rc = PTRS_OK;
@@ -529,21 +548,33 @@ struct HipBackend {
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
-        void **slots16[] = {(void **)&P.ray_o, (void **)&P.ray_d, (void **)&P.beta, (void **)&P.L, (void **)&P.st, (void **)&P.hit, (void **)&P.pfilm, (void **)&P.nee0,
-                            (void **)&P.nee1, (void **)&P.nee2, (void **)&P.sh_o, (void **)&P.sh_d, (void **)&P.mis_o, (void **)&P.mis_d};
-        int w = 0;
-        for (auto s : slots16) { if ((rc = ps->ws[w].ensure(n16)) != PTRS_OK) { err = g_err; return rc; } *s = ps->ws[w++].p; }
-        void **slots4[] = {(void **)&Q.ext[0], (void **)&Q.ext[1], (void **)&Q.nee};
-        for (auto s : slots4) { if ((rc = ps->ws[w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } *s = ps->ws[w++].p; }
-        for (int k = 0; k < Q_NUM_MAT; ++k) {
-            Q.mat[k] = nullptr;
-            if (kinds_mask & (1u << k)) { if ((rc = ps->ws[w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } Q.mat[k] = (uint32_t *)ps->ws[w].p; }
-            ++w;
+        if ((rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
+        for (uint32_t l = 0; l < n_lanes && n_lanes > 1; ++l) {
+            if (l > 0 && !ps->lane_stream[l] && hipStreamCreateWithFlags(&ps->lane_stream[l], hipStreamNonBlocking) != hipSuccess) { err = "cannot create a pipeline stream"; return PTRS_ERR_DEVICE; }
+            if (!ps->lane_ev[l] && hipEventCreateWithFlags(&ps->lane_ev[l], hipEventDisableTiming) != hipSuccess) { err = "cannot create pipeline events"; return PTRS_ERR_DEVICE; }
         }
-        if ((rc = ps->counts.ensure((size_t)rows * Q_STRIDE * (size_t)grid_max * 4)) != PTRS_OK || (rc = ps->totals.ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK || (rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
-        Q.counts = (uint32_t *)ps->counts.p; Q.stats = (unsigned long long *)ps->stats.p;
+        for (uint32_t l = 0; l < n_lanes; ++l) {
+            DPaths Pl; DQueues Ql;
+            void **slots16[] = {(void **)&Pl.ray_o, (void **)&Pl.ray_d, (void **)&Pl.beta, (void **)&Pl.L, (void **)&Pl.st, (void **)&Pl.hit, (void **)&Pl.pfilm, (void **)&Pl.nee0,
+                                (void **)&Pl.nee1, (void **)&Pl.nee2, (void **)&Pl.sh_o, (void **)&Pl.sh_d, (void **)&Pl.mis_o, (void **)&Pl.mis_d};
+            int w = 0;
+            for (auto sl : slots16) { if ((rc = ps->ws[l][w].ensure(n16)) != PTRS_OK) { err = g_err + " (path state of pipeline lane " + std::to_string(l) + "; PTRS_LANES=1 halves the workspace)"; return rc; } *sl = ps->ws[l][w++].p; }
+            void **slots4[] = {(void **)&Ql.ext[0], (void **)&Ql.ext[1], (void **)&Ql.nee};
+            for (auto sl : slots4) { if ((rc = ps->ws[l][w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } *sl = ps->ws[l][w++].p; }
+            for (int k = 0; k < Q_NUM_MAT; ++k) {
+                Ql.mat[k] = nullptr;
+                if (kinds_mask & (1u << k)) { if ((rc = ps->ws[l][w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } Ql.mat[k] = (uint32_t *)ps->ws[l][w].p; }
+                ++w;
+            }
+            if ((rc = ps->counts[l].ensure((size_t)rows * Q_STRIDE * (size_t)grid_max * 4)) != PTRS_OK || (rc = ps->totals[l].ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK) { err = g_err; return rc; }
+            Ql.counts = (uint32_t *)ps->counts[l].p; Ql.stats = (unsigned long long *)ps->stats.p;
+            lane_[l] = Lane{l == 0 ? stream : ps->lane_stream[l], DParams{}, Pl, Ql, 1u, 0u};
+        }
+        cur = 0; P = lane_[0].P; Q = lane_[0].Q;
         float tab[256]; gaussian_filter_table(tab);
         if (hipMemcpyAsync(ps->table.p, tab, 1024, hipMemcpyHostToDevice, stream) != hipSuccess || hipMemsetAsync(Q.stats, 0, CNT_NUM * 8, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { err = "workspace initialisation failed"; return PTRS_ERR_DEVICE; }
+        // fork: the second lane starts after everything the caller had queued on its stream (now drained) -- nothing to wait for
+        film_prev = nullptr;
         return PTRS_OK;
     }
     // per pass: G workgroups (= queue segments), each segment holds at most seg_cap entries
@@ -559,8 +590,9 @@ struct HipBackend {
 
     template <int FEAT> void extend_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
-        const StackSpill sp = ps->spill;
+        StackSpill sp = ps->spill;
         const bool ovf = sp.p != nullptr;
+        if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill && sc.n_nodes4) {
             if (ps->stack_lds == 8) { if (ovf) hipLaunchKernelGGL((k_extend_rf<FEAT, 8, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, 8, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); }
             else { if (ovf) hipLaunchKernelGGL((k_extend_rf<FEAT, 16, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, 16, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); }
@@ -578,8 +610,9 @@ struct HipBackend {
     void extend(uint32_t it) { t0(0); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void connect_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
-        const StackSpill sp = ps->spill;
+        StackSpill sp = ps->spill;
         const bool ovf = sp.p != nullptr;
+        if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
 #define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap)
         if (ps->stack_lds == 8) {
             if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
@@ -601,7 +634,7 @@ struct HipBackend {
         }
     }
     void shade(uint32_t it, int kind) { t0(1); if (feat == FEAT_FULL) shade_t<FEAT_FULL>(it, kind); else shade_t<FEAT_SIMPLE>(it, kind); t1(); }
-    void reduce_counts(uint32_t n_rows) { hipLaunchKernelGGL(k_reduce_counts, dim3(n_rows * Q_STRIDE), dim3(BLOCK), 0, stream, (const uint32_t *)Q.counts, G, (uint32_t *)ps->totals.p); }
+    void reduce_counts(uint32_t n_rows) { hipLaunchKernelGGL(k_reduce_counts, dim3(n_rows * Q_STRIDE), dim3(BLOCK), 0, stream, (const uint32_t *)Q.counts, G, (uint32_t *)ps->totals[cur].p); }
     uint32_t read_count(uint32_t it, int q) {
         std::vector<uint32_t> seg(G);
         (void)hipMemcpyAsync(seg.data(), Q.counts + ((size_t)it * Q_STRIDE + (size_t)q) * G, (size_t)G * 4, hipMemcpyDeviceToHost, stream);
@@ -611,16 +644,20 @@ struct HipBackend {
     }
     void read_counts(uint32_t *dst, uint32_t n_rows) {
         reduce_counts(n_rows);
-        (void)hipMemcpyAsync(dst, ps->totals.p, (size_t)n_rows * Q_STRIDE * 4, hipMemcpyDeviceToHost, stream);
+        (void)hipMemcpyAsync(dst, ps->totals[cur].p, (size_t)n_rows * Q_STRIDE * 4, hipMemcpyDeviceToHost, stream);
         if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE;
     }
     void film(v4 *film_px, int32_t y0, int32_t y1) {
         const int32_t tiles_x = (R.W + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
+        // film kernels run in pass order whichever lane they are on: the film is one running sum per pixel
+        if (n_lanes > 1 && film_prev) (void)hipStreamWaitEvent(stream, film_prev, 0);
         t0(2); hipLaunchKernelGGL(k_film, dim3((uint32_t)tiles_x * (uint32_t)tiles_y), dim3(BLOCK), 0, stream, R, S, P, (const float *)ps->table.p, film_px, y0, y1, tiles_x); t1();
+        if (n_lanes > 1) { film_prev = ps->lane_ev[cur]; (void)hipEventRecord(film_prev, stream); }
     }
     void export_samples(float *out) { t0(2); hipLaunchKernelGGL(k_export_samples, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, P, out); t1(); }
     void end(PtrsStats &st) {
-        if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE;
+        for (uint32_t l = 0; l < n_lanes; ++l) { select(l); if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE; }
+        select(0);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { g_err = std::string("kernel launch failed: ") + hipGetErrorString(le); rc = PTRS_ERR_DEVICE; }
         unsigned long long hs[CNT_NUM] = {0};
@@ -632,8 +669,9 @@ struct HipBackend {
             if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.cat == 0) st.ms_trace += ms; else if (s.cat == 1) st.ms_shade += ms; else st.ms_film += ms; }
         }
         size_t bytes = 0;
-        for (auto &b : ps->ws) bytes += b.bytes;
-        st.device_bytes = bytes + ps->counts.bytes + ps->film_tmp.bytes + ps->samples_tmp.bytes;
+        for (auto &l : ps->ws) for (auto &b : l) bytes += b.bytes;
+        for (auto &b : ps->counts) bytes += b.bytes;
+        st.device_bytes = bytes + ps->film_tmp.bytes + ps->samples_tmp.bytes;
     }
 };
 
@@ -698,7 +736,8 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     ps->stack_lds = (!H.use_quad || H.stack_bound <= 12 || (force && atoi(force) == 8)) ? 8u : 16u; // pair form (LDS-staged scenes) only exists with the 8-entry column
     if (H.stack_bound > ps->stack_lds) {
         const size_t threads = (size_t)ps->n_cu * 8 * BLOCK;
-        if ((rc = ps->stack_spill.ensure(threads * (size_t)(H.stack_bound - ps->stack_lds) * sizeof(unsigned long long))) != PTRS_OK) { delete ps; return rc; }
+        ps->spill_lane_elems = threads * (size_t)(H.stack_bound - ps->stack_lds);
+        if ((rc = ps->stack_spill.ensure(ps->spill_lane_elems * MAX_LANES * sizeof(unsigned long long))) != PTRS_OK) { delete ps; return rc; } // concurrent lanes must not share columns
         ps->spill.p = (unsigned long long *)ps->stack_spill.p; ps->spill.stride = (uint32_t)threads;
     }
     *out = ps;

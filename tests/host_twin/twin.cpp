@@ -67,6 +67,8 @@ struct HostBackend {
         Q.counts = alloc<uint32_t>((size_t)rows * Q_STRIDE); Q.stats = alloc<unsigned long long>(CNT_NUM);
         return PTRS_OK;
     }
+    uint32_t lanes() const { return 1; }
+    void select(uint32_t) {}
     void pass_begin(const DParams &R_) { R = R_; std::memset(Q.counts, 0, (size_t)rows * Q_STRIDE * 4); }
     uint32_t &cnt(uint32_t it, int q) { return Q.counts[(size_t)it * Q_STRIDE + q]; }
     void generate() {

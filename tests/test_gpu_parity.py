@@ -155,6 +155,22 @@ def test_fused_extension_kernel_on_a_large_scene(ptrs, orc, scenes, monkeypatch)
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
 
 
+def test_pipeline_lanes_do_not_change_the_film(ptrs, monkeypatch):
+    """Passes overlap on several pipeline lanes (streams with their own path state); the film kernels are chained
+    in pass order, so the accumulators must be bit-identical to a single-lane render."""
+    films = []
+    for lanes in ("1", "2", "4"):
+        monkeypatch.setenv("PTRS_LANES", lanes)
+        cam, scene = ptrs.import_scene(CORNELL, (96, 80))
+        integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(16, cam.film.get_sample_bounds()), 6, paths_per_pass=30000)  # 6+ passes
+        integ.render(cam, scene)
+        assert integ.last_stats.passes >= 6
+        films.append(cam.film.pixels.copy())
+    for f in films[1:]:
+        assert np.array_equal(f["rgb"].view(np.uint32), films[0]["rgb"].view(np.uint32))
+        assert np.array_equal(f["weight"].view(np.uint32), films[0]["weight"].view(np.uint32))
+
+
 def test_full_size_properties(ptrs):
     """BASELINE configs[1] at full size (1024x1024, depth 15; 16 spp to stay within the test budget):
     size-independent properties -- filter-weight sums are the analytic constant in the interior,
