@@ -481,6 +481,7 @@ struct PtrsScene {
     DevBuf stack_spill;  // global part of the traversal stacks (trees deeper than the LDS column), one column per resident thread
     StackSpill spill{nullptr, 0};
     size_t spill_lane_elems = 0;
+    int grid_mult = 1; // workgroups (= queue segments) per pass in units of the resident capacity (8 per CU)
     uint32_t stack_lds = 16; // LDS stack entries per lane: 8 when the tree allows it, else 16 (+ spill)
     // render workspace, grown on demand and reused across calls
     DevBuf ws[MAX_LANES][32];   // per pipeline lane
@@ -543,7 +544,7 @@ struct HipBackend {
 
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
-        grid_max = ps->n_cu * 8;
+        grid_max = ps->n_cu * 8 * ps->grid_mult;
         if (const char *e = getenv("PTRS_REFILL")) { int v = atoi(e); refill = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
@@ -734,8 +735,9 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     // LDS column (with spill) on any scene -- a test hook for the spill path.
     const char *force = getenv("PTRS_STACK_LDS");
     ps->stack_lds = (!H.use_quad || H.stack_bound <= 12 || (force && atoi(force) == 8)) ? 8u : 16u; // pair form (LDS-staged scenes) only exists with the 8-entry column
+    if (const char *gm = getenv("PTRS_GRID_MULT")) { int v = atoi(gm); ps->grid_mult = v < 1 ? 1 : (v > 16 ? 16 : v); }
     if (H.stack_bound > ps->stack_lds) {
-        const size_t threads = (size_t)ps->n_cu * 8 * BLOCK;
+        const size_t threads = (size_t)ps->n_cu * 8 * ps->grid_mult * BLOCK;
         ps->spill_lane_elems = threads * (size_t)(H.stack_bound - ps->stack_lds);
         if ((rc = ps->stack_spill.ensure(ps->spill_lane_elems * MAX_LANES * sizeof(unsigned long long))) != PTRS_OK) { delete ps; return rc; } // concurrent lanes must not share columns
         ps->spill.p = (unsigned long long *)ps->stack_spill.p; ps->spill.stride = (uint32_t)threads;
@@ -820,7 +822,7 @@ int ptrs_trace_rays(PtrsScene *scene, uint32_t n, const float *rays, int32_t any
     if ((rc = upload(bo, ro)) || (rc = upload(bd, rd)) || (rc = bh.ensure((size_t)n * 16)) || (rc = bc.ensure(16)) || (rc = bs.ensure(CNT_NUM * 8)) || (rc = bt.ensure((size_t)n * 4))) { bo.release(); bd.release(); bh.release(); bc.release(); bs.release(); bt.release(); return rc; }
     hipError_t e = hipMemcpy(bc.p, &n, 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(bs.p, 0, CNT_NUM * 8);
-    const uint32_t gmax = (uint32_t)scene->n_cu * 8u; // the spill columns are sized for this many workgroups
+    const uint32_t gmax = (uint32_t)scene->n_cu * 8u * (uint32_t)scene->grid_mult; // the spill columns are sized for this many workgroups
     dim3 g((n + BLOCK - 1) / BLOCK > gmax ? gmax : (n + BLOCK - 1) / BLOCK), b(BLOCK);
     hipEvent_t ea, eb; (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
     (void)hipEventRecord(ea, nullptr);
