@@ -99,6 +99,52 @@ PT_HD bool alpha_rejects(const DScene &sc, uint32_t prim, int32_t alpha_tex, con
 //     when it is popped: the same subtrees are entered as in the reference, which matters when two
 //     coincident surfaces compete at (rounded-)equal t.
 // n_nodes counts child boxes tested, n_tris triangle tests.
+template <bool ANY, class Stack>
+PT_HD uint32_t pop_next_ref(Stack &stack, float t_max) {
+    while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) return r; }
+    return REF_NONE;
+}
+
+// One pair-node visit: tests both children, stacks the far one when both are hit and returns the next reference in `cur`.
+template <bool ANY, class Stack, class Geom>
+PT_HD void pair_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes) {
+    v4 a, b, c, e;
+    G.node(cur, a, b, c, e);
+    const uint32_t ref0 = f2u(e.x), ref1 = f2u(e.y), axis = f2u(e.z);
+    n_nodes += 2;
+    float t0 = 0.0f, t1 = 0.0f;
+    const bool h0 = slab_entry6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t0) & (t0 < t_max);
+    const bool h1 = (ref1 != REF_NONE) & slab_entry6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t1) & (t1 < t_max);
+    const bool second_first = axis < 3u && neg[axis];
+    const uint32_t near_ref = second_first ? ref1 : ref0, far_ref = second_first ? ref0 : ref1;
+    const bool near_hit = second_first ? h1 : h0, far_hit = second_first ? h0 : h1;
+    if (near_hit) { if (far_hit) stack.push(far_ref, second_first ? t0 : t1); cur = near_ref; }
+    else if (far_hit) cur = far_ref;
+    else cur = pop_next_ref<ANY>(stack, t_max);
+}
+
+// The leaf's triangles, in order (a later hit with equal t replaces the earlier one, Q14).  Returns true when an
+// any-hit query (compile-time ANY, or any_rt for kernels that mix both kinds of rays in one loop) is done.
+template <bool ANY, bool ALPHA, class Geom>
+PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, const RayShear &shear, float &t_max, HitRec &out, bool &hit, uint32_t &n_tris, bool any_rt = false) {
+    const uint32_t leaf_first = leaf & REF_FIRST_MASK, leaf_count = ((leaf >> REF_COUNT_SHIFT) & 15u) + 1u;
+    for (uint32_t i = 0; i < leaf_count; ++i) {
+        v4 ta, tb, tc;
+        G.tri(leaf_first + i, ta, tb, tc);
+        const f3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
+        const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
+        ++n_tris;
+        TriHit h;
+        if (tri_test_s(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
+            if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) continue;
+            if (ANY || any_rt) { out.prim = 0; hit = true; return true; }
+            hit = true; t_max = h.t;
+            out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
+        }
+    }
+    return false;
+}
+
 template <bool ANY, bool ALPHA, class Stack, class Geom>
 PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
     out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f; out.flags = 0;
@@ -110,75 +156,12 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     uint32_t cur = 0; // reference to process next (interior index or leaf), REF_NONE when done
     bool hit = false;
     while (cur != REF_NONE) {
-        // phase 1: descend through interior nodes until a leaf is reached
-        while (cur != REF_NONE && !(cur & REF_LEAF)) {
-            v4 a, b, c, e;
-            G.node(cur, a, b, c, e);
-            const uint32_t ref0 = f2u(e.x), ref1 = f2u(e.y), axis = f2u(e.z);
-            n_nodes += 2;
-            float t0 = 0.0f, t1 = 0.0f;
-            const bool h0 = slab_entry6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t0) & (t0 < t_max);
-            const bool h1 = (ref1 != REF_NONE) & slab_entry6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t1) & (t1 < t_max);
-            const bool second_first = axis < 3u && neg[axis];
-            const uint32_t near_ref = second_first ? ref1 : ref0, far_ref = second_first ? ref0 : ref1;
-            const bool near_hit = second_first ? h1 : h0, far_hit = second_first ? h0 : h1;
-            if (near_hit) { if (far_hit) stack.push(far_ref, second_first ? t0 : t1); cur = near_ref; }
-            else if (far_hit) cur = far_ref;
-            else {
-                cur = REF_NONE;
-                while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
-            }
-        }
+        while (cur != REF_NONE && !(cur & REF_LEAF)) pair_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes); // descend to a leaf
         if (cur == REF_NONE) break;
-        // phase 2: the leaf's triangles, in order
-        const uint32_t leaf_first = cur & REF_FIRST_MASK, leaf_count = ((cur >> REF_COUNT_SHIFT) & 15u) + 1u;
-        for (uint32_t i = 0; i < leaf_count; ++i) {
-            v4 ta, tb, tc;
-            G.tri(leaf_first + i, ta, tb, tc);
-            const f3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
-            const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
-            ++n_tris;
-            TriHit h;
-            if (tri_test_s(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
-                if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) continue;
-                if (ANY) { out.prim = 0; return true; }
-                hit = true; t_max = h.t;
-                out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
-            }
-        }
-        cur = REF_NONE;
-        while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) { cur = r; break; } }
+        if (leaf_test<ANY, ALPHA>(G, sc, cur, o, shear, t_max, out, hit, n_tris)) return true;                   // its triangles, in order
+        cur = pop_next_ref<ANY>(stack, t_max);
     }
     return hit;
-}
-
-
-// The leaf's triangles, in order (a later hit with equal t replaces the earlier one, Q14).  Returns true when an
-// any-hit query is done.
-template <bool ANY, bool ALPHA, class Geom>
-PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, const RayShear &shear, float &t_max, HitRec &out, bool &hit, uint32_t &n_tris) {
-    const uint32_t leaf_first = leaf & REF_FIRST_MASK, leaf_count = ((leaf >> REF_COUNT_SHIFT) & 15u) + 1u;
-    for (uint32_t i = 0; i < leaf_count; ++i) {
-        v4 ta, tb, tc;
-        G.tri(leaf_first + i, ta, tb, tc);
-        const f3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
-        const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
-        ++n_tris;
-        TriHit h;
-        if (tri_test_s(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
-            if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) continue;
-            if (ANY) { out.prim = 0; return true; }
-            hit = true; t_max = h.t;
-            out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
-        }
-    }
-    return false;
-}
-
-template <bool ANY, class Stack>
-PT_HD uint32_t pop_next_ref(Stack &stack, float t_max) {
-    while (!stack.empty()) { uint32_t r; float te; stack.pop(r, te); if (ANY || te < t_max) return r; }
-    return REF_NONE;
 }
 
 // One quad-node visit: tests the node's slots, stacks the postponed ones and returns the next reference in `cur`
@@ -212,6 +195,11 @@ PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg
     else {
         cur = pop_next_ref<ANY>(stack, t_max);
     }
+}
+
+template <bool QUAD, bool ANY, class Stack, class Geom>
+PT_HD void node_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes) {
+    if (QUAD) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes); else pair_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes);
 }
 
 // Quad-node traversal (DNode4): one fetch covers two levels of the binary tree.  Slots are visited in the order the

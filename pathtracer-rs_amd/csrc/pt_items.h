@@ -232,27 +232,23 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 // The two scene queries of estimate_direct and its use of their results: shadow any-hit
 // (integrator.rs:66-78, light.rs:38-42), MIS closest hit (119-134), then `l += beta * nLights * ld`
 // (444-446, 206-216).  One NEE record per call.
-template <int FEAT, bool QUAD, class Stack, class Geom>
-PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t pid, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
+// The part of estimate_direct after its two scene queries: `occluded` is the shadow ray's answer, `mh` the MIS ray's
+// closest hit (prim < 0: it escaped).
+template <int FEAT>
+PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid, bool occluded, const HitRec &mh) {
     const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
     const u4 n2 = P.nee2[pid];
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
     f3 ld = splat3(0.0f);
-    if (fl & NEE_SHADOW) {
-        const v4 o = P.sh_o[pid], d = P.sh_d[pid];
-        HitRec h;
-        if (!bvh_trace_g<QUAD, true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris)) ld = ld + xyz(n0);
-    }
+    if ((fl & NEE_SHADOW) && !occluded) ld = ld + xyz(n0);
     if (fl & NEE_MIS) {
         const DLight &Lt = sc.lights[li];
-        const v4 o = P.mis_o[pid];
         const f3 wi = xyz(P.mis_d[pid]);
-        HitRec h;
         f3 l2 = splat3(0.0f);
-        if (bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), wi, PT_INF, stack, h, n_nodes, n_tris)) {
-            const TriRegs T = load_tri_regs(sc.shade + h.prim);
+        if (mh.prim >= 0) {
+            const TriRegs T = load_tri_regs(sc.shade + mh.prim);
             if (T.light == (int32_t)li) { // std::ptr::eq(light, isect_light) (Q11)
-                Surface s = tri_surface(T, h.prim, h.b0, h.b1, h.b2, -wi);
+                Surface s = tri_surface(T, mh.prim, mh.b0, mh.b1, mh.b2, -wi);
                 l2 = surface_le<FEAT>(sc, T, s, -wi);
             }
         } else l2 = light_le<FEAT>(sc, Lt, wi);
@@ -262,6 +258,23 @@ PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32
     const v4 Lv = P.L[pid];
     const f3 L = xyz(Lv) + beta * ((float)sc.n_lights * ld);
     P.L[pid] = mkv4(L, Lv.w);
+}
+
+template <int FEAT, bool QUAD, class Stack, class Geom>
+PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t pid, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
+    const uint32_t fl = P.nee2[pid].w >> 24;
+    bool occluded = false;
+    HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
+    if (fl & NEE_SHADOW) {
+        const v4 o = P.sh_o[pid], d = P.sh_d[pid];
+        HitRec h;
+        occluded = bvh_trace_g<QUAD, true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris);
+    }
+    if (fl & NEE_MIS) {
+        const v4 o = P.mis_o[pid];
+        if (!bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(P.mis_d[pid]), PT_INF, stack, mh, n_nodes, n_tris)) mh.prim = -1;
+    }
+    resolve_item<FEAT>(sc, P, pid, occluded, mh);
 }
 
 // run-time material dispatch (host twin; the HIP back end launches one specialised kernel per bucket)

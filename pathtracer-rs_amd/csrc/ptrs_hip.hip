@@ -194,62 +194,140 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpi
 // and, once at least `thresh` lanes of the wave are idle, takes the next ray of the workgroup's queue segment from an
 // LDS cursor.  The per-path epilogue (emission, environment, material bucketing) would run with a handful of lanes each
 // time, so it moves to k_epilogue, which walks the same segment with full waves afterwards.
-template <int FEAT, int DEPTH, bool OVF>
+// Per-lane ray state of the refill kernels: plain scalars on purpose (a struct with the sign array in it made hipcc
+// produce a 20 % slower loop).
+#define RF_DECL f3 r_o = mk3(0, 0, 0), r_inv = mk3(1, 1, 1); bool r_neg[3] = {false, false, false}; RayShear r_shear; r_shear.kz = 2; r_shear.sx = r_shear.sy = 0.0f; r_shear.sz = 1.0f; \
+                float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE;
+#define RF_START(O, D, TMAX) { r_o = (O); const f3 d_ = (D); r_tmax = (TMAX); r_inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); \
+                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_shear = ray_shear(d_); \
+                r_h.prim = -1; r_h.t = r_tmax; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; r_hit = false; r_cur = 0; }
+// next index of the workgroup's segment for every idle lane of the wave (one LDS atomic per wave)
+__device__ inline uint32_t rf_take(uint32_t *cursor, unsigned long long idle) {
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)idle) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(idle));
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+}
+
+template <int FEAT, int DEPTH, bool OVF, int GEOM>
 __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
+    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
     __shared__ uint32_t cursor;
-    const GeomGlobal G = geom_global(sc);
+    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
     if (threadIdx.x == 0) cursor = 0;
-    __syncthreads();
+    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
     const uint32_t Gn = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_EXT, Gn, b);
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-    uint32_t nn = 0, nt = 0;
-    uint32_t pid = 0, cur = REF_NONE;
+    uint32_t nn = 0, nt = 0, pid = 0;
     bool has = false, dry = n == 0; // has: the lane holds an unfinished ray; dry: the segment has no rays left for this wave
-    f3 o = mk3(0, 0, 0), inv = mk3(1, 1, 1);
-    bool neg[3] = {false, false, false};
-    RayShear shear; shear.kz = 2; shear.sx = shear.sy = 0.0f; shear.sz = 1.0f;
-    float t_max = 0.0f; bool hit = false;
-    HitRec h; h.prim = -1; h.t = 0.0f; h.b0 = h.b1 = h.b2 = 0.0f; h.flags = 0;
+    RF_DECL
     for (;;) {
-        if (has && cur == REF_NONE) { // retire: the hit record is all that leaves this kernel
-            u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
-            P.hit[pid] = r;
+        if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this kernel
+            u4 v; v.x = (uint32_t)r_h.prim; v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
+            P.hit[pid] = v;
             has = false;
         }
         const unsigned long long idle = __ballot(!has);
         if (!dry && (uint32_t)__popcll(idle) >= thresh) {
             if (!has) {
-                const int lane = (int)__lane_id();
-                const int leader = __ffsll((long long)idle) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&cursor, (uint32_t)__popcll(idle));
-                base = (uint32_t)__shfl((int)base, leader);
-                const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t i = rf_take(&cursor, idle);
                 if (i < n) {
                     pid = queue[i];
                     const v4 ov = P.ray_o[pid], dv = P.ray_d[pid];
-                    o = xyz(ov); const f3 d = xyz(dv); t_max = ov.w;
-                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    neg[0] = inv.x < 0.0f; neg[1] = inv.y < 0.0f; neg[2] = inv.z < 0.0f;
-                    shear = ray_shear(d);
-                    h.prim = -1; h.t = t_max; h.b0 = h.b1 = h.b2 = 0.0f; h.flags = 0; hit = false;
-                    stk.clear(); cur = 0; has = true;
+                    RF_START(xyz(ov), xyz(dv), ov.w)
+                    stk.clear(); has = true;
                 } else dry = true;
             }
-            // lanes that still hold rays learn that the segment is exhausted from the cursor
-            if (cursor >= n) dry = true;
+            if (cursor >= n) dry = true; // lanes that still hold rays learn that the segment is exhausted
         }
         if (!__any(has)) break; // every ray of the segment this wave could get is retired
-        while (cur != REF_NONE && !(cur & REF_LEAF)) quad_visit<false>(G, cur, o, inv, neg, t_max, stk, nn);
-        if (cur != REF_NONE) {
-            leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(G, sc, cur, o, shear, t_max, h, hit, nt);
-            cur = pop_next_ref<false>(stk, t_max);
+        if (GEOM > 0) {
+            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<false, false>(GL, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
+            if (r_cur != REF_NONE) { leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt); r_cur = pop_next_ref<false>(stk, r_tmax); }
+        } else {
+            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<true, false>(GG, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
+            if (r_cur != REF_NONE) { leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt); r_cur = pop_next_ref<false>(stk, r_tmax); }
         }
     }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
+}
+
+// The two scene queries of a pending NEE record with lane refill: a lane walks the shadow ray (any hit), then the MIS
+// ray (closest hit) of its record and leaves the answers in the path state (NEE_OCCLUDED in nee2.w, the MIS hit in
+// `hit`, which the shade stage has consumed by now); k_resolve turns them into radiance with full waves.
+template <int FEAT, int DEPTH, bool OVF, int GEOM>
+__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
+    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
+    __shared__ uint32_t cursor;
+    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
+    if (threadIdx.x == 0) cursor = 0;
+    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
+    const uint32_t Gn = gridDim.x, b = blockIdx.x;
+    const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_NEE, Gn, b);
+    LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
+    uint32_t nn = 0, nt = 0, pid = 0, fl = 0;
+    bool has = false, dry = n == 0, shadow_phase = false, setup = false;
+    RF_DECL
+    for (;;) {
+        if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
+            if (shadow_phase) {
+                if (r_hit) reinterpret_cast<uint32_t *>(P.nee2 + pid)[3] |= NEE_OCCLUDED << 24;
+                if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
+            } else {
+                u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
+                P.hit[pid] = v;
+                has = false;
+            }
+        }
+        const unsigned long long idle = __ballot(!has);
+        if (!dry && (uint32_t)__popcll(idle) >= thresh) {
+            if (!has) {
+                const uint32_t i = rf_take(&cursor, idle);
+                if (i < n) {
+                    pid = queue[i];
+                    fl = reinterpret_cast<const uint32_t *>(P.nee2 + pid)[3] >> 24;
+                    if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
+                } else dry = true;
+            }
+            if (cursor >= n) dry = true;
+        }
+        if (setup) {
+            if (shadow_phase) { const v4 o = P.sh_o[pid], d = P.sh_d[pid]; RF_START(xyz(o), xyz(d), o.w) }
+            else { const v4 o = P.mis_o[pid], d = P.mis_d[pid]; RF_START(xyz(o), xyz(d), PT_INF) }
+            stk.clear(); setup = false;
+        }
+        if (!__any(has)) break;
+        if (GEOM > 0) {
+            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<false, false>(GL, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
+            if (r_cur != REF_NONE) { const bool done = leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, shadow_phase); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax); }
+        } else {
+            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<true, false>(GG, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
+            if (r_cur != REF_NONE) { const bool done = leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, shadow_phase); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax); }
+        }
+    }
+    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
+}
+
+// estimate_direct's use of the two answers (integrator.rs:66-78, 121-134) and `l += beta * nLights * ld`, full waves
+template <int FEAT>
+__global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
+        const uint32_t pid = queue[i];
+        const uint32_t fl = P.nee2[pid].w >> 24;
+        HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
+        if (fl & NEE_MIS) { const u4 v = P.hit[pid]; mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
+        resolve_item<FEAT>(sc, P, pid, (fl & NEE_OCCLUDED) != 0, mh);
+    }
 }
 
 // The epilogue k_extend_rf leaves out: emission / environment / depth cut (integrator.rs:418-431) and material bucketing,
@@ -522,7 +600,8 @@ struct HipBackend {
         cur = l; stream = lane_[l].stream; R = lane_[l].R; P = lane_[l].P; Q = lane_[l].Q; G = lane_[l].G; seg_cap = lane_[l].seg_cap;
     }
     int grid_max = 2048;
-    uint32_t refill = 16; // idle-lane threshold of k_extend_rf (quad-node scenes); 0 = the fused k_extend everywhere (PTRS_REFILL)
+    uint32_t refill_connect = 16;
+    uint32_t refill = 16; // idle-lane threshold of the lane-refill kernels; 0 = the fused k_extend / k_connect (PTRS_REFILL)
     int rc = PTRS_OK;
     // timing
     struct Span { int cat; hipEvent_t a, b; };
@@ -545,6 +624,10 @@ struct HipBackend {
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
         grid_max = ps->n_cu * 8 * ps->grid_mult;
+        // measured (single lane, Mray/s): Cornell (pair form, LDS) extend-refill 5722 vs none 5560, with connect-refill 5666;
+        // colonnade (quad form) none 1517, extend 1698, both 1830
+        refill_connect = sc.n_nodes4 ? 16u : 0u;
+        if (const char *e = getenv("PTRS_REFILL_CONNECT")) { int v = atoi(e); refill_connect = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
         if (const char *e = getenv("PTRS_REFILL")) { int v = atoi(e); refill = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
@@ -594,9 +677,14 @@ struct HipBackend {
         StackSpill sp = ps->spill;
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
-        if (refill && sc.n_nodes4) {
-            if (ps->stack_lds == 8) { if (ovf) hipLaunchKernelGGL((k_extend_rf<FEAT, 8, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, 8, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); }
-            else { if (ovf) hipLaunchKernelGGL((k_extend_rf<FEAT, 16, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, 16, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); }
+        if (refill) {
+#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill)
+            if (ps->stack_lds == 8) {
+                if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
+                else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
+                else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
+            } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
+#undef PTRS_LAUNCH
             hipLaunchKernelGGL((k_epilogue<FEAT>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
             return;
         }
@@ -614,6 +702,17 @@ struct HipBackend {
         StackSpill sp = ps->spill;
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
+        if (refill_connect) {
+#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect)
+            if (ps->stack_lds == 8) {
+                if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
+                else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
+                else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
+            } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
+#undef PTRS_LAUNCH
+            hipLaunchKernelGGL((k_resolve<FEAT>), g, b, 0, stream, sc, P, Q, it, seg_cap);
+            return;
+        }
 #define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap)
         if (ps->stack_lds == 8) {
             if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }

@@ -146,13 +146,19 @@ def test_stack_spill_path_matches_oracle(ptrs, orc, scenes, monkeypatch):
 
 
 def test_fused_extension_kernel_on_a_large_scene(ptrs, orc, scenes, monkeypatch):
-    """PTRS_REFILL=0 selects the fused k_extend (traversal + epilogue in one kernel) instead of the lane-refill
-    kernel + k_epilogue that quad-node scenes use by default: same samples."""
-    monkeypatch.setenv("PTRS_REFILL", "0")
+    """PTRS_REFILL / PTRS_REFILL_CONNECT = 0 select the fused k_extend / k_connect instead of the lane-refill kernels
+    (+ k_epilogue / k_resolve); any combination and any idle-lane threshold must give the same samples."""
     cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
-    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
-    monkeypatch.setenv("PTRS_REFILL", "1")
-    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    for ext, con in (("0", "0"), ("1", "1"), ("0", "16"), ("64", "0")):
+        monkeypatch.setenv("PTRS_REFILL", ext)
+        monkeypatch.setenv("PTRS_REFILL_CONNECT", con)
+        _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    # and on an LDS-resident (pair-form) scene, where connect refill is off by default
+    cam, scene = ptrs.import_scene(CORNELL, (48, 48))
+    for ext, con in (("0", "0"), ("16", "16")):
+        monkeypatch.setenv("PTRS_REFILL", ext)
+        monkeypatch.setenv("PTRS_REFILL_CONNECT", con)
+        _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
 
 
 def test_pipeline_lanes_do_not_change_the_film(ptrs, monkeypatch):
