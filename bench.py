@@ -254,7 +254,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (TRAFFIC_PMC_DEFAULT if (world == 1 and args.workload == "cornell" and (args.spp, args.res, args.depth, args.paths_per_pass) == (SPP, WIDTH, DEPTH, 0)) else None),
                          "algorithmic_bytes_per_launch": rays_rank0 * b_ray / max(float(vals[6]), 1.0),
-                         "kernel": "k_extend + k_connect (BVH closest-hit / any-hit traversal; bytes and time summed over both)", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+                         "kernel": "the BVH traversal kernels: k_extend_rf + k_connect_rf (k_extend + k_connect where lane refill is off); bytes and time summed over both", "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                          "avg_launch_ms": float(vals[3]) / max(float(vals[6]), 1.0), "launches": int(float(vals[6])),
                          # path-state traffic of the wavefront design, reported apart from the traversal figure
                          "timing": "HIP events around every traversal launch inside the timed steps; passes overlap on %s pipeline lanes there, so a launch's span includes time it shared the GPU with the other lanes' kernels" % (os.environ.get("PTRS_LANES") or "3"),

@@ -242,6 +242,25 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             L.cdf_off = (uint32_t)H.distdata.size(); H.distdata.insert(H.distdata.end(), s.dist_cdf, s.dist_cdf + (nu + 1) * nv);
             L.fint_off = (uint32_t)H.distdata.size(); H.distdata.insert(H.distdata.end(), s.dist_func_int, s.dist_func_int + nv);
             L.mcdf_off = (uint32_t)H.distdata.size(); H.distdata.insert(H.distdata.end(), s.marg_cdf, s.marg_cdf + nv + 1);
+            // guide tables (pt_vec.h find_interval_cdf_guided): g = the table size rounded up to a power of two
+            auto add_guide = [&](const float *cdf, size_t n, uint32_t g) { // cdf has n+1 entries
+                size_t cnt = 0;
+                for (uint32_t k = 0; k <= g; ++k) {
+                    const float x = (float)k / (float)g;
+                    while (cnt < n + 1 && cdf[cnt] <= x) ++cnt;
+                    H.distdata.push_back(ptf_from_bits((uint32_t)cnt));
+                }
+            };
+            uint32_t gu = 1, gv = 1; while (gu < nu) gu <<= 1; while (gv < nv) gv <<= 1;
+            bool monotone = true; // the shortcut needs what Distribution1D::new produces anyway
+            for (size_t r = 0; r < nv && monotone; ++r) for (size_t k = 0; k < nu; ++k) if (!(s.dist_cdf[r * (nu + 1) + k] <= s.dist_cdf[r * (nu + 1) + k + 1])) { monotone = false; break; }
+            for (size_t k = 0; k < nv && monotone; ++k) if (!(s.marg_cdf[k] <= s.marg_cdf[k + 1])) monotone = false;
+            if (monotone && H.distdata.size() + (size_t)(gu + 1) * nv + gv + 1 < 0xffffffffull) {
+                L.guide_u = gu; L.guide_v = gv;
+                L.mguide_off = (uint32_t)H.distdata.size(); add_guide(s.marg_cdf, nv, gv);
+                L.cguide_off = (uint32_t)H.distdata.size();
+                for (size_t r = 0; r < nv; ++r) add_guide(s.dist_cdf + r * (nu + 1), nu, gu);
+            }
             H.inf_lights.push_back(i);
         } else if (s.kind != PTRS_LIGHT_POINT && s.kind != PTRS_LIGHT_DIRECTIONAL) { err = "unknown light kind"; return PTRS_ERR_UNSUPPORTED; }
     }

@@ -80,8 +80,8 @@ PT_HD float spherical_theta(f3 v) { return pt_acosf(clamp_(v.z, -1.0f, 1.0f)); }
 PT_HD float spherical_phi(f3 v) { float p = pt_atan2f(v.y, v.x); return p < 0.0f ? p + 2.0f * PT_PI : p; }
 
 // Distribution1D::sample_continuous (sampling.rs:159-182)
-PT_HD float dist1d_sample(const float *func, const float *cdf, float func_int, uint32_t n, float u, float &pdf, uint32_t &off) {
-    off = find_interval_cdf(cdf, n + 1, u);
+PT_HD float dist1d_sample(const float *func, const float *cdf, float func_int, uint32_t n, float u, float &pdf, uint32_t &off, const float *guide = nullptr, uint32_t g = 0) {
+    off = g ? find_interval_cdf_guided(cdf, n + 1, u, guide, g) : find_interval_cdf(cdf, n + 1, u);
     float du = u - cdf[off];
     if ((cdf[off + 1] - cdf[off]) > 0.0f) du /= cdf[off + 1] - cdf[off];
     pdf = func_int > 0.0f ? func[off] / func_int : 0.0f;
@@ -120,8 +120,9 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
     // infinite area light
     const float *D = sc.distdata;
     float pdf_v, pdf_u; uint32_t v, dummy;
-    float d1 = dist1d_sample(D + L.fint_off, D + L.mcdf_off, L.marg_int, (uint32_t)L.nv, u.y, pdf_v, v);
-    float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), D[L.fint_off + v], (uint32_t)L.nu, u.x, pdf_u, dummy);
+    float d1 = dist1d_sample(D + L.fint_off, D + L.mcdf_off, L.marg_int, (uint32_t)L.nv, u.y, pdf_v, v, D + L.mguide_off, L.guide_v);
+    float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), D[L.fint_off + v], (uint32_t)L.nu, u.x, pdf_u, dummy,
+                             D + L.cguide_off + (uint64_t)v * (L.guide_u + 1u), L.guide_u);
     float map_pdf = pdf_u * pdf_v;
     if (map_pdf == 0.0f) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; }
     float theta = d1 * PT_PI, phi = d0 * 2.0f * PT_PI;

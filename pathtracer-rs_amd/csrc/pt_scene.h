@@ -98,6 +98,9 @@ struct alignas(16) DLight {
     DTriShade T;                                                // area lights: a copy of the light's triangle record
     int32_t lmap_tex; int32_t nu, nv; float marg_int;
     uint32_t func_off, cdf_off, fint_off, mcdf_off;
+    // guide tables for the two cdf searches (0 = none): entry k of a table with g cells = the number of leading cdf
+    // values <= k/g, so the search for u only has to look between entries floor(u*g) and floor(u*g)+1
+    uint32_t guide_u, guide_v, cguide_off, mguide_off;
     float l2w[12], w2l[12];
 };
 

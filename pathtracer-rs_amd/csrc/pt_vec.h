@@ -126,6 +126,21 @@ PT_HD uint32_t find_interval_cdf(const float *cdf, uint32_t size, float u) {
     uint32_t v = first - 1u; // wraps when first == 0 (Q27), then clamps to size-2
     return v > size - 2u ? size - 2u : v;
 }
+// The same answer with a guide table: `guide` has g+1 entries (g a power of two), guide[k] = number of leading cdf values
+// <= k/g.  For u in [k/g, (k+1)/g) the count of values <= u lies in [guide[k], guide[k+1]], and bisecting that range with
+// the same predicate finds it: a monotone predicate has one switch-over point, whichever way it is approached.
+PT_HD uint32_t find_interval_cdf_guided(const float *cdf, uint32_t size, float u, const float *guide, uint32_t g) {
+    uint32_t k = u > 0.0f ? (uint32_t)(u * (float)g) : 0u; // exact: g is a power of two
+    if (k > g - 1u) k = g - 1u;
+    uint32_t first = ptf_bits(guide[k]), n = ptf_bits(guide[k + 1u]) - first;
+    if (u < 0.0f || !(u == u)) { first = 0; n = size; } // outside the table's domain: the plain search
+    while (n > 0) {
+        uint32_t half = n >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; n -= half + 1; } else n = half;
+    }
+    uint32_t v = first - 1u;
+    return v > size - 2u ? size - 2u : v;
+}
 // nalgebra UnitQuaternion(i,j,k,w) * Vector3
 PT_HD f3 quat_rotate(const float *q, f3 v) {
     f3 qv = mk3(q[0], q[1], q[2]);

@@ -685,6 +685,7 @@ struct HipBackend {
                 else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
             } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
+            t1(); t0(1); // the traversal span ends here: the epilogue is shading-side work
             hipLaunchKernelGGL((k_epilogue<FEAT>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
             return;
         }
@@ -710,6 +711,7 @@ struct HipBackend {
                 else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
             } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
+            t1(); t0(1);
             hipLaunchKernelGGL((k_resolve<FEAT>), g, b, 0, stream, sc, P, Q, it, seg_cap);
             return;
         }
