@@ -34,10 +34,10 @@ WIDTH, HEIGHT, SPP, DEPTH = 1024, 1024, 256, 15
 SCENE = os.path.join(ROOT, "tests", "golden", "cornell-box.xml")
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per traversal-kernel launch (k_extend + k_connect) for the DEFAULT workload on one GPU, from two
-# separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; profiles/r01_v5_pmc_fetch_write.csv, tools/summarize_pmc.py):
-# (83.37e6 + 150.85e6 KB fetched + 48.32e6 + 29.40e6 KB written) / 192 launches.  FETCH_SIZE is taken as
+# separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; profiles/r01_v8_pmc_fetch_write.csv, tools/summarize_pmc.py; single lane):
+# (83.36e6 + 255.52e6 KB fetched + 88.53e6 + 44.12e6 KB written) / 288 launches.  FETCH_SIZE is taken as
 # reported (gfx950 under-reports wide streaming reads by 2x; these are 16-byte gathers, uncalibrated).
-TRAFFIC_PMC_DEFAULT = (83.37e6 + 150.85e6 + 48.32e6 + 29.40e6) * 1024.0 / 192.0
+TRAFFIC_PMC_DEFAULT = (83.36e6 + 255.52e6 + 88.53e6 + 44.12e6) * 1024.0 / 288.0
 
 
 def host_cores():
