@@ -240,3 +240,58 @@ def test_film_matches_twin_bitwise(ptrs, orc):
     ft, _, _ = twin.TwinScene(scene).render(cam, orc.make_params(70, 45, 8, 6, paths_per_pass=40000))
     assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ft["rgb"].view(np.uint32))
     assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), ft["weight"].view(np.uint32))
+
+
+def _tiny_scene(ptrs, kind):
+    """Degenerate inputs the reference's own code paths have to survive (and so must the GPU path)."""
+    abi = ptrs.abi
+    s = ptrs.RenderScene()
+    white = s.add_material(abi.MAT_MATTE, [s.const_rgb([0.7, 0.7, 0.7])])
+    tri = np.array([[-1, 0, -3], [1, 0, -3], [0, 1.5, -3]], np.float32)
+    if kind == "one_triangle_emissive":      # whole scene = one leaf (root is a leaf): single-slot node
+        s.add_mesh(tri, np.array([[0, 1, 2]], np.uint32), white, emission_rgb=[3.0, 2.0, 1.0])
+    elif kind == "no_lights":                # uniform_sample_one_light returns before drawing samples
+        s.add_mesh(tri, np.array([[0, 1, 2]], np.uint32), white)
+        s.add_mesh(tri + np.array([0, 0, -1], np.float32), np.array([[0, 2, 1]], np.uint32), white)
+    elif kind == "degenerate_and_duplicate":  # zero-area triangle, coincident duplicates (ties), point light
+        pos = np.array([[-2, -1, -4], [2, -1, -4], [2, 2, -4], [-2, 2, -4], [0, 0, -3.5], [0, 0, -3.5], [0, 0, -3.5]], np.float32)
+        idx = np.array([[0, 1, 2], [0, 2, 3], [0, 1, 2], [4, 5, 6], [0, 2, 3]], np.uint32)
+        s.add_mesh(pos, idx, white)
+        s.add_point_light([0.5, 0.5, -1.0], [8.0, 8.0, 8.0])
+    elif kind == "null_bsdf_glass_stack":     # black glass = no BSDF: the path skips the surfaces with bounces -= 1 (Q7)
+        glass = s.add_material(abi.MAT_GLASS, [s.const_rgb([0, 0, 0]), s.const_rgb([0, 0, 0]), s.const_f(1.5)])
+        for k in range(5):
+            s.add_mesh(tri * np.float32(2) + np.array([0, -1, 0.2 * k], np.float32), np.array([[0, 1, 2]], np.uint32), glass)
+        s.add_mesh(tri * np.float32(4) + np.array([0, -2, -2], np.float32), np.array([[0, 1, 2]], np.uint32), white, emission_rgb=[2.0, 2.0, 2.0])
+    cam = ptrs.look_at_camera([0.0, 0.5, 1.5], [0.0, 0.5, -3.0], [0, 1, 0], 50.0, (24, 16))
+    return cam, s
+
+
+@pytest.mark.parametrize("kind", ["one_triangle_emissive", "no_lights", "degenerate_and_duplicate", "null_bsdf_glass_stack"])
+@pytest.mark.parametrize("spp,depth", [(1, 0), (4, 15)])
+def test_edge_scenes_match_oracle(ptrs, orc, kind, spp, depth):
+    cam, scene = _tiny_scene(ptrs, kind)
+    _gpu_vs_oracle_film_tolerant(ptrs, orc, cam, scene, spp, depth)
+
+
+def _gpu_vs_oracle_film_tolerant(ptrs, orc, cam, scene, spp, depth):
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(spp, cam.film.get_sample_bounds()), depth)
+    samples = integ.render(cam, scene, want_samples=True)
+    st = integ.last_stats
+    film_ref, ref, ost = orc.OracleScene(scene).render(cam, orc.make_params(cam.film.width, cam.film.height, spp, depth), n_threads=4, want_samples=True)
+    assert (st.samples, st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.samples, ost.rays_extension, ost.rays_shadow, ost.rays_mis)
+    assert np.array_equal(samples.view(np.uint32), ref.view(np.uint32))
+    a, b = cam.film.pixels, film_ref
+    assert np.allclose(a["weight"], b["weight"], rtol=1e-5) and np.allclose(a["rgb"], b["rgb"], rtol=1e-4, atol=1e-7)
+
+
+def test_render_single_pixel_on_the_gpu(ptrs, orc):
+    """PathIntegrator::render_single_pixel (integrator.rs:505-534) through ptrs_render_single_pixel."""
+    cam, scene = ptrs.import_scene(CORNELL, (40, 40))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(8, cam.film.get_sample_bounds()), 6)
+    p = orc.make_params(40, 40, 8, 6)
+    O = orc.OracleScene(scene)
+    for px, py in ((0, 0), (17, 23), (39, 39), (-2, 5), (41, 39)):  # incl. the filter apron left and right of the film rows
+        got = integ.render_single_pixel(cam, (px, py), scene)
+        want = O.render_single_pixel(cam, p, px, py)
+        assert np.array_equal(np.asarray(got).view(np.uint32), want.view(np.uint32))
