@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/ptrs.h"
+#include "pt_light.h"
 #include "pt_tri.h"
 
 namespace pt {
@@ -264,7 +265,32 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             H.inf_lights.push_back(i);
         } else if (s.kind != PTRS_LIGHT_POINT && s.kind != PTRS_LIGHT_DIRECTIONAL) { err = "unknown light kind"; return PTRS_ERR_UNSUPPORTED; }
     }
-    for (auto &L : H.lights) if (L.kind == PTRS_LIGHT_AREA) L.T = H.shade[L.tri];
+    for (auto &L : H.lights) if (L.kind == PTRS_LIGHT_AREA) {
+        L.T = H.shade[L.tri];
+        // Triangle::sample and pdf_at_point end with a face-forwarded geometric normal.  When every vertex normal lies
+        // clearly on one side of the triangle's plane the sign cannot depend on the barycentrics: run the device code
+        // at seven points, require identical bits, and let the kernels use the constant (pt_light.h).
+        const TriRegs T = load_tri_regs(&L.T);
+        bool ok = !(T.flags & TRI_DEGENERATE);
+        if (ok && (T.flags & TRI_HAS_NORMAL)) {
+            const f3 g = normalize(cross(T.p0 - T.p2, T.p1 - T.p2));
+            const float d0 = dot(g, T.n0) / len(T.n0), d1 = dot(g, T.n1) / len(T.n1), d2 = dot(g, T.n2) / len(T.n2);
+            ok = (d0 > 0.05f && d1 > 0.05f && d2 > 0.05f) || (d0 < -0.05f && d1 < -0.05f && d2 < -0.05f);
+        }
+        if (ok) {
+            static const float B[7][2] = {{1, 0}, {0, 1}, {0, 0}, {0.5f, 0.5f}, {0.5f, 0}, {0, 0.5f}, {0.3333f, 0.3333f}};
+            f3 ns0 = splat3(0.0f), np0 = splat3(0.0f);
+            for (int k = 0; k < 7 && ok; ++k) {
+                f3 p, n, perr; f2 uv;
+                tri_point_normal(T, B[k][0], B[k][1], 1.0f - B[k][0] - B[k][1], p, n);
+                const float su0 = 1.0f - B[k][0]; // b0 = 1 - sqrt(u0), b1 = u1 sqrt(u0)
+                f3 n2; tri_sample(T, mk2(su0 * su0, su0 > 0.0f ? B[k][1] / su0 : 0.0f), p, n2, perr, uv);
+                if (k == 0) { np0 = n; ns0 = n2; }
+                else ok = f2u(n.x) == f2u(np0.x) && f2u(n.y) == f2u(np0.y) && f2u(n.z) == f2u(np0.z) && f2u(n2.x) == f2u(ns0.x) && f2u(n2.y) == f2u(ns0.y) && f2u(n2.z) == f2u(ns0.z);
+            }
+            if (ok && np0.x == np0.x && ns0.x == ns0.x) { L.n_ok = 1u; L.n_point[0] = np0.x; L.n_point[1] = np0.y; L.n_point[2] = np0.z; L.n_sample[0] = ns0.x; L.n_sample[1] = ns0.y; L.n_sample[2] = ns0.z; }
+        }
+    }
     // ---- accelerator ----------------------------------------------------------------------------
     std::vector<uint32_t> order;
     if (d.bvh_nodes && d.n_bvh_nodes) {

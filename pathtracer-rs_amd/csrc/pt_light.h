@@ -16,17 +16,20 @@ struct LightSample {
 };
 
 // Triangle::sample (shape.rs:541-578): point, face-forwarded normal, error bound, uv
-PT_HD void tri_sample(const TriRegs &T, f2 u, f3 &p, f3 &n, f3 &perr, f2 &uv) {
+PT_HD void tri_sample(const TriRegs &T, f2 u, f3 &p, f3 &n, f3 &perr, f2 &uv, const float *n_fixed = nullptr) {
     float su0 = sqrt_(u.x);
     float b0 = 1.0f - su0, b1 = u.y * su0;
     f3 p0 = T.p0, p1 = T.p1, p2 = T.p2;
     float b2 = 1.0f - b0 - b1;
     p = (b0 * p0) + (b1 * p1) + b2 * p2;
-    n = normalize(cross(p1 - p0, p2 - p0));
-    if (T.flags & TRI_HAS_NORMAL) {
-        f3 ns = (b0 * T.n0) + (b1 * T.n1) + b2 * T.n2;
-        n = face_forward(n, ns);
-    } else if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) n = n * -1.0f;
+    if (n_fixed) n = ld3(n_fixed); // the build checked that the lines below give this for every (b0, b1, b2)
+    else {
+        n = normalize(cross(p1 - p0, p2 - p0));
+        if (T.flags & TRI_HAS_NORMAL) {
+            f3 ns = (b0 * T.n0) + (b1 * T.n1) + b2 * T.n2;
+            n = face_forward(n, ns);
+        } else if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) n = n * -1.0f;
+    }
     perr = gamma_err(6) * (abs3(b0 * p0) + abs3(b1 * p1) + abs3(b2 * p2));
     uv = mk2(b0 * T.uv0.x + b1 * T.uv1.x + b2 * T.uv2.x, b0 * T.uv0.y + b1 * T.uv1.y + b2 * T.uv2.y);
 }
@@ -61,7 +64,7 @@ PT_HD void tri_point_normal(const TriRegs &T, float b0, float b1, float b2, f3 &
 
 // Triangle::pdf_at_point (shape.rs:62-72): a single-triangle intersection from the offset origin
 template <int FEAT>
-PT_HD float tri_pdf_at_point(const DScene &sc, const TriRegs &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi) {
+PT_HD float tri_pdf_at_point(const DScene &sc, const TriRegs &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi, const float *n_fixed = nullptr) {
     f3 o = spawn_origin(ref_p, ref_err, ref_n, wi);
     TriHit h;
     if (!tri_test(o, wi, PT_INF, T.p0, T.p1, T.p2, h)) return 0.0f;
@@ -71,7 +74,8 @@ PT_HD float tri_pdf_at_point(const DScene &sc, const TriRegs &T, float area, f3 
         if (tex_eval<FEAT>(sc, T.alpha_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f).x == 0.0f) return 0.0f;
     }
     f3 p, n;
-    tri_point_normal(T, h.b0, h.b1, h.b2, p, n);
+    if (n_fixed) { p = h.b0 * T.p0 + h.b1 * T.p1 + h.b2 * T.p2; n = ld3(n_fixed); }
+    else tri_point_normal(T, h.b0, h.b1, h.b2, p, n);
     return len2(ref_p - p) / (fabs_(dot(n, -wi)) * area);
 }
 
@@ -108,9 +112,9 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
     if (L.kind == 2) { // diffuse area light on one triangle (its record is embedded in the light)
         const TriRegs T = load_tri_regs(&L.T);
         f3 p, n, perr; f2 uv;
-        tri_sample(T, u, p, n, perr, uv);
+        tri_sample(T, u, p, n, perr, uv, L.n_ok ? L.n_sample : nullptr);
         o.wi = normalize(p - ref_p);
-        o.pdf = tri_pdf_at_point<FEAT>(sc, T, L.area, ref_p, ref_err, ref_n, o.wi);
+        o.pdf = tri_pdf_at_point<FEAT>(sc, T, L.area, ref_p, ref_err, ref_n, o.wi, L.n_ok ? L.n_point : nullptr);
         o.p1 = p; o.p1_err = perr; o.p1_n = n;
         f3 w = -o.wi;
         o.li = dot(n, w) > 0.0f ? (L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f)) : splat3(0.0f);
@@ -136,7 +140,7 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
 
 template <int FEAT>
 PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f3 w) {
-    if (L.kind == 2) return tri_pdf_at_point<FEAT>(sc, load_tri_regs(&L.T), L.area, ref_p, ref_err, ref_n, w);
+    if (L.kind == 2) return tri_pdf_at_point<FEAT>(sc, load_tri_regs(&L.T), L.area, ref_p, ref_err, ref_n, w, L.n_ok ? L.n_point : nullptr);
     if ((FEAT & FEAT_INFINITE) && L.kind == 3) {
         f3 wi = xform_vec(L.w2l, w);
         float theta = spherical_theta(wi), phi = spherical_phi(wi);

@@ -101,6 +101,10 @@ struct alignas(16) DLight {
     // guide tables for the two cdf searches (0 = none): entry k of a table with g cells = the number of leading cdf
     // values <= k/g, so the search for u only has to look between entries floor(u*g) and floor(u*g)+1
     uint32_t guide_u, guide_v, cguide_off, mguide_off;
+    // area lights: the normals Triangle::sample and pdf_at_point's intersection end up with, when they do not depend on
+    // where the triangle is hit (n_ok; checked at build time): both are +-(a geometric normal), the sign decided by
+    // face-forwarding to the interpolated shading normal
+    float n_sample[3]; uint32_t n_ok; float n_point[3]; uint32_t pad_n;
     float l2w[12], w2l[12];
 };
 

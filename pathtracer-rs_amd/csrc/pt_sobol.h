@@ -31,10 +31,6 @@ PT_HD uint32_t pixel_scramble(int32_t x, int32_t y) {
 // bit-serial loop, which remains as the fallback for dimensions beyond the table.
 PT_HD float sobol_sample(const DSampler &S, uint64_t index, uint32_t dim, uint32_t scramble) {
     uint32_t v = scramble;
-#ifdef PTRS_PROBE_NOSOBOL // perf probe only (breaks parity): what does shade cost without the table lookups?
-    v ^= (uint32_t)index * 2654435761u + dim * 40503u;
-    return min_(PT_ONE_MINUS_EPS, (float)v * 0x1p-32f);
-#endif
     if (S.bytetab && dim < (uint32_t)SOBOL_TAB_DIMS) {
         const uint32_t *t = S.bytetab + (size_t)dim * (8u * 256u);
         uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
