@@ -103,6 +103,15 @@ PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P
     return (int)((h.flags >> TRI_BUCKET_SHIFT) & 7u); // material bucket, carried by the leaf triangle record
 }
 
+// The extension hit's first word: triangle id in bits 0..26 (REF_FIRST_MASK bounds the triangle count), the leaf record's
+// material bucket in bits 27..29 and its is-light flag in bit 30, so the epilogue kernel needs no gather from the triangle
+// table; 0xffffffff = no hit.
+PT_HD uint32_t hit_pack(int32_t prim, uint32_t flags) {
+    return prim < 0 ? 0xffffffffu : ((uint32_t)prim | (((flags >> TRI_BUCKET_SHIFT) & 7u) << 27) | ((flags & TRI_IS_LIGHT) ? 1u << 30 : 0u));
+}
+PT_HD int32_t hit_prim(uint32_t x) { return x == 0xffffffffu ? -1 : (int32_t)(x & REF_FIRST_MASK); }
+PT_HD uint32_t hit_flags(uint32_t x) { return x == 0xffffffffu ? 0u : ((((x >> 27) & 7u) << TRI_BUCKET_SHIFT) | (((x >> 30) & 1u) ? (uint32_t)TRI_IS_LIGHT : 0u)); }
+
 struct ShadeResult { bool next; bool nee; bool shadow; bool mis; };
 
 template <int MAT, int FEAT>
@@ -115,7 +124,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     float eta_scale = bv.w;
     u4 stv = P.st[pid];
     u4 h = P.hit[pid];
-    const int32_t prim = (int32_t)h.x;
+    const int32_t prim = hit_prim(h.x);
     const TriRegs T = load_tri_regs(sc.shade + prim);
     int32_t bounces = st_bounces(stv.z);
     PathCoord c = path_coord(R, S, pid);

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpi
         HitRec h;
         if (GEOM > 0) bvh_trace_g<false, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt); // pair nodes in LDS
         else bvh_trace_g<true, false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);           // quad nodes through L1/L2
-        u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
+        u4 r; r.x = hit_pack(h.prim, h.flags); r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
         P.hit[pid] = r;
         const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
         for (int m = 0; m < 6; ++m) { // wavefront-ballot bucketing by material kind
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
     RF_DECL
     for (;;) {
         if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this kernel
-            u4 v; v.x = (uint32_t)r_h.prim; v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
+            u4 v; v.x = hit_pack(r_h.prim, r_h.flags); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
             P.hit[pid] = v;
             has = false;
         }
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
         if (i < n) {
             pid = queue[i];
             const u4 r = P.hit[pid];
-            HitRec h; h.prim = (int32_t)r.x; h.t = 0.0f; h.b0 = u2f(r.y); h.b1 = u2f(r.z); h.b2 = u2f(r.w);
-            h.flags = h.prim >= 0 ? sc.shade[h.prim].flags : 0u; // same flags word as the leaf record's
+            HitRec h; h.prim = hit_prim(r.x); h.t = 0.0f; h.b0 = u2f(r.y); h.b1 = u2f(r.z); h.b2 = u2f(r.w);
+            h.flags = hit_flags(r.x); // the two fields of the leaf record's flags the epilogue reads
             k = extension_epilogue<FEAT>(R, sc, P, pid, h);
         }
         for (int m = 0; m < 6; ++m) {

@@ -83,7 +83,7 @@ struct HostBackend {
             CheckedStack stk = make_stack(); HitRec h; uint32_t nn = 0, nt = 0;
             bvh_trace_any_form<false, (FEAT & FEAT_ALPHA) != 0>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
             nodes += nn; tris += nt;
-            u4 r; r.x = (uint32_t)h.prim; r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
+            u4 r; r.x = hit_pack(h.prim, h.flags); r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
             const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
             if (k >= 0) Q.mat[k][cnt(it, Q_MAT0 + k)++] = pid;
         }
