@@ -1,4 +1,5 @@
-// pt_bvh.h -- BVH traversal over the flattened 32-byte-node tree.
+// pt_bvh.h -- BVH traversal over pair nodes (LDS-resident scenes) and quad nodes (everything else), both derived
+// from the flattened 32-byte-node binary tree.
 //
 // Restates BVH::intersect / intersect_p (src/pathtracer/accelerator.rs:359-475) and
 // Bounds3::intersect_p_precomp (src/common/bounds.rs:190-232): near-child-first by split axis,
@@ -11,29 +12,6 @@
 namespace pt {
 
 struct HitRec { int32_t prim; float t, b0, b1, b2; uint32_t flags; };
-
-PT_HD bool slab_test(const v4 &a, const v4 &b, f3 o, f3 inv, const bool neg[3], float t_max) {
-    // a = (pmin.xyz, pmax.x)   b = (pmax.y, pmax.z, offset, meta)
-    const float k = 1.0f + 2.0f * gamma_err(3);
-    float lox = neg[0] ? a.w : a.x, hix = neg[0] ? a.x : a.w;
-    float loy = neg[1] ? b.x : a.y, hiy = neg[1] ? a.y : b.x;
-    float loz = neg[2] ? b.y : a.z, hiz = neg[2] ? a.z : b.y;
-    float t_min = (lox - o.x) * inv.x;
-    float t_mx = (hix - o.x) * inv.x;
-    float ty_min = (loy - o.y) * inv.y;
-    float ty_max = (hiy - o.y) * inv.y;
-    t_mx *= k; ty_max *= k;
-    if (t_min > ty_max || ty_min > t_mx) return false;
-    if (ty_min > t_min) t_min = ty_min;
-    if (ty_max < t_mx) t_mx = ty_max;
-    float tz_min = (loz - o.z) * inv.z;
-    float tz_max = (hiz - o.z) * inv.z;
-    tz_max *= k;
-    if (t_min > tz_max || tz_min > t_mx) return false;
-    if (tz_min > t_min) t_min = tz_min;
-    if (tz_max < t_mx) t_mx = tz_max;
-    return (t_min < t_max) && (t_mx > 0.0f);
-}
 
 // Where traversal reads geometry from.  GeomGlobal: the HBM arrays (through L1/L2).  GeomLocal:
 // a 16-byte-vector copy [4 per pair node | 3 per triangle] -- on gfx950 the kernels stage small scenes

@@ -3,7 +3,7 @@
 // One wavefront stage = one kernel.  Every queue-driven kernel is launched with a fixed persistent
 // grid (CUs x 8 workgroups of 256 threads = 4 wave64 per workgroup) and grid-strides over a queue
 // whose length it reads from device memory, so a whole pass is enqueued without host round trips.
-// Queue compaction uses one wave-aggregated atomic per wave (64-bit ballot + mbcnt prefix).
+// Queues are segmented per workgroup; slots come from LDS counters (one ds_add per wave), never from global atomics.
 // The traversal stack lives in LDS, one column of 8-byte (node ref, entry distance) records per lane; on
 // trees deeper than the LDS column the excess spills to a per-thread column in global memory.
 //
@@ -39,18 +39,6 @@ thread_local std::string g_err;
     } while (0)
 
 constexpr int BLOCK = 256;
-
-// ---- wave-aggregated queue push (wave64) ----------------------------------------------------------
-__device__ inline uint32_t wave_push(uint32_t *counter, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return 0xffffffffu;
-    const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
 
 // Segmented queues.  Every queue is split into G segments (G = grid size of the pass); workgroup b
 // appends only to segment b and, in the next kernel, workgroup b consumes segment b.  Slots are
@@ -360,10 +348,6 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
     if (threadIdx.x < 6 && (kinds_mask & (1u << threadIdx.x))) *seg_count(Q, it, Q_MAT0 + (int)threadIdx.x, G, b) = lcount[threadIdx.x];
 }
 
-__device__ inline void wave_count(uint32_t *counter, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m != 0ull && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(counter, (uint32_t)__popcll(m));
-}
 
 // One instantiation per material kind (and feature set): lobe kinds are compile-time constants.
 // Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X: the Matte / FEAT_SIMPLE kernel (175

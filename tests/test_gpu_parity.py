@@ -295,3 +295,21 @@ def test_render_single_pixel_on_the_gpu(ptrs, orc):
         got = integ.render_single_pixel(cam, (px, py), scene)
         want = O.render_single_pixel(cam, p, px, py)
         assert np.array_equal(np.asarray(got).view(np.uint32), want.view(np.uint32))
+
+
+def test_cfg5_band_with_33_bit_sobol_indices(ptrs, orc, scenes):
+    """BASELINE configs[4] settings (3840x2160, 512 spp, depth 15: Sobol indices need 33 bits, m = 12) on a 2-row band
+    of a reduced-detail colonnade: the whole pipeline with the index's high word in the path state, against the oracle."""
+    cam, scene = scenes.colonnade((3840, 2160), detail=0.01, tex_size=64)
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(512, cam.film.get_sample_bounds()), 15)
+    rb, re = 1000, 1002
+    integ.render(cam, scene, row_begin=rb, row_end=re)  # (the per-sample export would be 51 GB at this size)
+    st = integ.last_stats
+    p = orc.make_params(3840, 2160, 512, 15, row_begin=rb, row_end=re)
+    film_ref, _, ost = orc.OracleScene(scene).render(cam, p, n_threads=16)
+    assert st.samples == ost.samples == 3844 * 6 * 512
+    # identical ray counts over 11.8 M paths: every branch decision (hits, lobe picks, Russian roulette) agreed
+    assert (st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.rays_extension, ost.rays_shadow, ost.rays_mis)
+    a, b = cam.film.pixels[rb:re], film_ref[rb:re]
+    assert (b["weight"] > 0).all()
+    assert np.allclose(a["weight"], b["weight"], rtol=1e-5) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-5
