@@ -312,4 +312,5 @@ def test_cfg5_band_with_33_bit_sobol_indices(ptrs, orc, scenes):
     assert (st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.rays_extension, ost.rays_shadow, ost.rays_mis)
     a, b = cam.film.pixels[rb:re], film_ref[rb:re]
     assert (b["weight"] > 0).all()
-    assert np.allclose(a["weight"], b["weight"], rtol=1e-5) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-5
+    # 12 800 binary32 additions per pixel in two different orders (the reference's own order depends on tile scheduling)
+    assert np.allclose(a["weight"], b["weight"], rtol=1e-4) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-4
