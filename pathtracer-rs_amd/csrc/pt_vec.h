@@ -38,8 +38,9 @@ PT_HD float ceil_(float x) { return __builtin_ceilf(x); }
 PT_HD bool isinf_(float x) { return (ptf_bits(x) & 0x7fffffffu) == 0x7f800000u; }
 PT_HD bool isnan_(float x) { return x != x; }
 // Rust f32::max / f32::min (a NaN operand is ignored) and f32::clamp
-PT_HD float max_(float a, float b) { return a != a ? b : (b != b ? a : (a > b ? a : b)); }
-PT_HD float min_(float a, float b) { return a != a ? b : (b != b ? a : (a < b ? a : b)); }
+// (written as three independent selects: the nested-ternary form compiles to exec-mask branches on gfx950)
+PT_HD float max_(float a, float b) { const float m = a > b ? a : b; const float r = b != b ? a : m; return a != a ? b : r; }
+PT_HD float min_(float a, float b) { const float m = a < b ? a : b; const float r = b != b ? a : m; return a != a ? b : r; }
 PT_HD float clamp_(float x, float lo, float hi) { if (x < lo) x = lo; if (x > hi) x = hi; return x; }
 
 struct f2 { float x, y; };
