@@ -184,8 +184,9 @@ def _compare_full(abi, dump, cam_p, scene):
             assert np.float32(c["marg_func_int"]) == np.float32(d["marg_func_int"])
 
 
-def _write_rgbe(path, img):
-    """Flat (non-RLE) Radiance file from an (rows, cols, 3) float32 image."""
+def _write_rgbe(path, img, rle=False):
+    """Radiance file from an (rows, cols, 3) float32 image: flat scanlines, or the new-style per-channel RLE
+    (runs of equal bytes as `128 + n, value`, other bytes as literal blocks `n, bytes...`)."""
     img = np.asarray(img, dtype=np.float32)
     m = img.max(axis=-1)
     e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0).astype(np.int32)
@@ -195,7 +196,29 @@ def _write_rgbe(path, img):
     rgbe[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
     with open(path, "wb") as f:
         f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % img.shape[:2])
-        f.write(rgbe.tobytes())
+        if not rle:
+            f.write(rgbe.tobytes())
+            return
+        rows, cols = img.shape[:2]
+        assert 8 <= cols <= 0x7FFF
+        for y in range(rows):
+            f.write(bytes([2, 2, cols >> 8, cols & 255]))
+            for c in range(4):
+                row = rgbe[y, :, c]
+                x = 0
+                while x < cols:
+                    run = 1
+                    while x + run < cols and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, int(row[x])]))
+                        x += run
+                    else:
+                        lit = 1
+                        while x + lit < cols and lit < 128 and not (x + lit + 2 < cols and row[x + lit] == row[x + lit + 1] == row[x + lit + 2]):
+                            lit += 1
+                        f.write(bytes([lit]) + row[x:x + lit].tobytes())
+                        x += lit
 
 
 @pytest.mark.parametrize("glb", [False, True])
@@ -218,7 +241,7 @@ def test_cpp_gltf_default_camera_and_env_light(cli, ptrs, scenes, tmp_path):
     nocam = str(tmp_path / "nocam.gltf")
     json.dump(doc, open(nocam, "w"))
     hdr = str(tmp_path / "env.hdr")
-    _write_rgbe(hdr, scenes.synthetic_env_map(16, 32))
+    _write_rgbe(hdr, scenes.synthetic_env_map(16, 32), rle=True)  # both hosts' readers on the RLE form
     dump = str(tmp_path / "full.dump")
     subprocess.check_call([cli, nocam, "--dump-scene-full", dump, "-r", "80x40", "--default_lights", "--env_map", hdr])
     cam_p, scene = ptrs.import_scene(nocam, (80, 40), default_lights=True, env_map=hdr)

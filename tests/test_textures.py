@@ -43,3 +43,17 @@ def test_rgbe_reader_on_reference_asset(tx):
     assert img.shape == (512, 1024, 3) and img.dtype == np.float32
     assert np.isfinite(img).all() and img.min() >= 0 and 1e3 < img.max() < 1e6
     assert 0.2 < img.mean() < 2.0
+
+
+def test_rgbe_reader_flat_and_rle_agree(tx, scenes, tmp_path):
+    """The same image written as flat scanlines and as new-style RLE decodes to the same floats, c * 2^(e-136)."""
+    from test_host_cpp import _write_rgbe
+    img = scenes.synthetic_env_map(16, 32)
+    img[3, 5:20] = img[3, 5]  # a long run
+    a, b = str(tmp_path / "flat.hdr"), str(tmp_path / "rle.hdr")
+    _write_rgbe(a, img)
+    _write_rgbe(b, img, rle=True)
+    assert os.path.getsize(b) != os.path.getsize(a)
+    fa, fb = tx.read_rgbe(a), tx.read_rgbe(b)
+    assert fa.shape == (16, 32, 3) and np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+    assert (np.abs(fa - img) <= img.max(axis=-1, keepdims=True) / 128).all()  # 8-bit mantissas under the pixel's shared exponent
