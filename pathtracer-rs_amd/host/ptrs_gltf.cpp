@@ -5,8 +5,8 @@
 //   pathtracer/light.rs:331-398          InfiniteAreaLight::new (RGBE map, Distribution2D)
 // in the arithmetic order of pathtracer-rs_amd/{gltf,textures}.py, so both hosts hand the C ABI the same bits
 // (tests/test_host_cpp.py).  Third-party behaviour (gltf 1.1.0, image 0.23.14, nalgebra-glm) is restated from the
-// crates' published semantics: parity unpinned, see DESIGN.md.  Images: PNG only (own inflate-based decoder);
-// JPEG is reported as unsupported.  The quirks listed at the top of gltf.py are kept here as well.
+// crates' published semantics: parity unpinned, see DESIGN.md.  Images: PNG (own inflate-based decoder) and baseline
+// JPEG (own decoder, within a level or two of other decoders).  The quirks listed at the top of gltf.py are kept here as well.
 #include <zlib.h>
 
 #include <cmath>
@@ -123,7 +123,7 @@ std::string dir_of(const std::string &p) { size_t k = p.find_last_of('/'); retur
 struct Image8 { int w = 0, h = 0, ch = 0; std::vector<uint8_t> px; bool supported = false; };
 bool decode_png(const std::string &d, Image8 &img, std::string &err) {
     static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (d.size() < 8 || std::memcmp(d.data(), sig, 8) != 0) { err = (d.size() > 2 && (unsigned char)d[0] == 0xFF && (unsigned char)d[1] == 0xD8) ? "JPEG images are not supported by the C++ host" : "unknown image format"; return false; }
+    if (d.size() < 8 || std::memcmp(d.data(), sig, 8) != 0) { err = "unknown image format"; return false; }
     auto be32 = [&](size_t o) { return ((uint32_t)(uint8_t)d[o] << 24) | ((uint32_t)(uint8_t)d[o + 1] << 16) | ((uint32_t)(uint8_t)d[o + 2] << 8) | (uint32_t)(uint8_t)d[o + 3]; };
     size_t o = 8; uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
     std::string idat; std::vector<uint8_t> plte, trns;
@@ -183,6 +183,146 @@ bool decode_png(const std::string &d, Image8 &img, std::string &err) {
     for (uint32_t y = 0; y < h; ++y) for (size_t k = 0; k < (size_t)w * nch; ++k) img.px[(size_t)y * w * nch + k] = (uint8_t)sample(y, k);
     img.supported = (nch == 3 || nch == 4) && depth == 8; // R8, R8G8 and 16-bit formats: "unsupported image format" (gltf.rs:91-97)
     return true;
+}
+
+// ---- baseline JPEG decoder (sequential DCT, Huffman, 8 bit; 1 or 3 components; restart intervals) ---------------------
+// The reference decodes JPEG through image 0.23 / jpeg-decoder; IDCT rounding and chroma upsampling differ between
+// decoders by a level or so, so JPEG textures are close to, not bit-identical with, any other host's (parity unpinned).
+// Here: separable binary64 IDCT, libjpeg-style triangle chroma upsampling (2x1, 2x2), JFIF YCbCr -> RGB.  Progressive
+// files are refused.
+struct JpegDec {
+    const uint8_t *p; size_t n, pos = 0; std::string err;
+    uint8_t qt[4][64]{}; bool have_qt[4]{};
+    struct Huff { uint8_t bits[17]{}; uint8_t vals[256]{}; int mincode[17]{}, maxcode[18]{}, valptr[17]{}; bool ok = false; } dc[4], ac[4];
+    struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; std::vector<uint8_t> plane; int pw = 0, ph = 0; } comp[3];
+    int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0;
+    uint32_t bitbuf = 0; int bitcnt = 0; bool hit_marker = false;
+    JpegDec(const std::string &d) : p((const uint8_t *)d.data()), n(d.size()) {}
+    bool fail(const char *m) { if (err.empty()) err = m; return false; }
+    int u8() { return pos < n ? p[pos++] : 0; }
+    int u16() { int a = u8(); return (a << 8) | u8(); }
+    void build(Huff &h) {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) { h.valptr[l] = k; h.mincode[l] = code; code += h.bits[l]; k += h.bits[l]; h.maxcode[l] = h.bits[l] ? code - 1 : -1; code <<= 1; }
+        h.maxcode[17] = 0x7fffffff; h.ok = true;
+    }
+    int bit() {
+        if (bitcnt == 0) {
+            int b = 0;
+            if (!hit_marker && pos < n) { b = p[pos++]; if (b == 0xFF) { int b2 = pos < n ? p[pos] : 0; if (b2 == 0) ++pos; else { hit_marker = true; --pos; b = 0; } } }
+            bitbuf = (uint32_t)b; bitcnt = 8;
+        }
+        --bitcnt; return (int)((bitbuf >> bitcnt) & 1u);
+    }
+    int bits(int k) { int v = 0; while (k-- > 0) v = (v << 1) | bit(); return v; }
+    int decode(const Huff &h) {
+        int code = 0;
+        for (int l = 1; l <= 16; ++l) { code = (code << 1) | bit(); if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]]; }
+        return -1;
+    }
+    static int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
+    bool block(Comp &c, int bx, int by) {
+        static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                      35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        double coef[64] = {0};
+        int t = decode(dc[c.td]); if (t < 0 || t > 11) return fail("bad JPEG DC code");
+        c.pred += extend(bits(t), t);
+        coef[0] = (double)c.pred * qt[c.tq][0];
+        for (int k = 1; k < 64;) {
+            const int rs = decode(ac[c.ta]); if (rs < 0) return fail("bad JPEG AC code");
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+            k += r; if (k > 63) return fail("JPEG coefficient overrun");
+            coef[zz[k]] = (double)extend(bits(sz), sz) * qt[c.tq][k]; ++k;
+        }
+        static double cs[8][8]; static bool init = false;
+        if (!init) { for (int x = 0; x < 8; ++x) for (int u = 0; u < 8; ++u) cs[x][u] = (u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0); init = true; }
+        double tmp[64];
+        for (int v = 0; v < 8; ++v) for (int x = 0; x < 8; ++x) { double a = 0; for (int u = 0; u < 8; ++u) a += cs[x][u] * coef[8 * v + u]; tmp[8 * v + x] = a; }
+        for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
+            double a = 0; for (int v = 0; v < 8; ++v) a += cs[y][v] * tmp[8 * v + x];
+            const int px = 8 * bx + x, py = 8 * by + y;
+            if (px < c.pw && py < c.ph) { double q = std::floor(a + 128.5); c.plane[(size_t)py * c.pw + px] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q)); }
+        }
+        return true;
+    }
+    bool run(Image8 &img) {
+        if (n < 4 || p[0] != 0xFF || p[1] != 0xD8) return fail("not a JPEG file");
+        pos = 2;
+        for (;;) {
+            if (pos + 4 > n) return fail("truncated JPEG");
+            if (u8() != 0xFF) return fail("JPEG marker expected");
+            int m = u8(); while (m == 0xFF) m = u8();
+            if (m == 0xD9) return fail("JPEG without image data");
+            const size_t seg = pos; const int len = u16();
+            if (len < 2 || seg + len > n) return fail("bad JPEG segment length");
+            if (m == 0xDB) { while (pos < seg + len) { const int pq = u8(); if (pq >> 4) return fail("16-bit JPEG quantisation tables are not supported"); for (int k = 0; k < 64; ++k) qt[pq & 3][k] = (uint8_t)u8(); have_qt[pq & 3] = true; } }
+            else if (m == 0xC4) { while (pos < seg + len) { const int th = u8(); Huff &h = (th >> 4) ? ac[th & 3] : dc[th & 3]; int tot = 0; for (int l = 1; l <= 16; ++l) { h.bits[l] = (uint8_t)u8(); tot += h.bits[l]; } if (tot > 256) return fail("bad JPEG Huffman table"); for (int k = 0; k < tot; ++k) h.vals[k] = (uint8_t)u8(); build(h); } }
+            else if (m == 0xC0 || m == 0xC1) {
+                if (u8() != 8) return fail("only 8-bit JPEG is supported");
+                H = u16(); W = u16(); ncomp = u8();
+                if ((ncomp != 1 && ncomp != 3) || W <= 0 || H <= 0) return fail("unsupported JPEG component count");
+                for (int i = 0; i < ncomp; ++i) { comp[i].id = u8(); const int hv = u8(); comp[i].h = hv >> 4; comp[i].v = hv & 15; comp[i].tq = u8() & 3; if (comp[i].h < 1 || comp[i].h > 2 || comp[i].v < 1 || comp[i].v > 2) return fail("unsupported JPEG sampling factors"); hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v); }
+            } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) return fail("progressive / arithmetic JPEG is not supported by the C++ host");
+            else if (m == 0xDD) restart = u16();
+            else if (m == 0xDA) {
+                if (!W) return fail("JPEG scan before frame header");
+                const int ns = u8(); if (ns != ncomp) return fail("non-interleaved JPEG scans are not supported");
+                for (int i = 0; i < ns; ++i) { const int id = u8(), t = u8(); for (int j = 0; j < ncomp; ++j) if (comp[j].id == id) { comp[j].td = t >> 4; comp[j].ta = t & 15; } }
+                pos = seg + len;
+                const int mcuw = 8 * hmax, mcuh = 8 * vmax, mx = (W + mcuw - 1) / mcuw, my = (H + mcuh - 1) / mcuh;
+                for (int i = 0; i < ncomp; ++i) { Comp &c = comp[i]; c.pw = mx * 8 * c.h; c.ph = my * 8 * c.v; c.plane.assign((size_t)c.pw * c.ph, 0); if (!have_qt[c.tq] || !dc[c.td].ok || !ac[c.ta].ok) return fail("JPEG table missing"); }
+                int todo = restart;
+                for (int yy = 0; yy < my; ++yy) for (int xx = 0; xx < mx; ++xx) {
+                    if (restart && todo == 0) { // RSTn: byte-align, skip the marker, reset predictors
+                        bitcnt = 0; hit_marker = false;
+                        while (pos + 1 < n && !(p[pos] == 0xFF && p[pos + 1] >= 0xD0 && p[pos + 1] <= 0xD7)) ++pos;
+                        pos += 2; for (int i = 0; i < ncomp; ++i) comp[i].pred = 0; todo = restart;
+                    }
+                    for (int i = 0; i < ncomp; ++i) for (int by = 0; by < comp[i].v; ++by) for (int bx = 0; bx < comp[i].h; ++bx) if (!block(comp[i], xx * comp[i].h + bx, yy * comp[i].v + by)) return false;
+                    if (restart) --todo;
+                }
+                break;
+            }
+            pos = seg + len;
+        }
+        img.w = W; img.h = H; img.ch = ncomp == 1 ? 1 : 3; img.px.resize((size_t)W * H * img.ch);
+        // chroma planes to full resolution: libjpeg's "fancy" (triangle) upsampling for 2x1 and 2x2, as jpeg-decoder does
+        std::vector<uint8_t> full[3];
+        for (int i = 0; i < ncomp; ++i) {
+            const Comp &k = comp[i];
+            const int fw = k.pw * hmax / k.h, fh = k.ph * vmax / k.v;
+            full[i].resize((size_t)fw * fh);
+            auto at = [&](int x, int y) -> int { x = x < 0 ? 0 : (x >= k.pw ? k.pw - 1 : x); y = y < 0 ? 0 : (y >= k.ph ? k.ph - 1 : y); return k.plane[(size_t)y * k.pw + x]; };
+            const int fx = hmax / k.h, fy = vmax / k.v;
+            for (int y = 0; y < fh; ++y) for (int x = 0; x < fw; ++x) {
+                int v;
+                if (fx == 1 && fy == 1) v = at(x, y);
+                else if (fx == 2 && fy == 1) { const int c = x >> 1; v = (x & 1) ? (3 * at(c, y) + at(c + 1, y) + 2) >> 2 : (3 * at(c, y) + at(c - 1, y) + 1) >> 2; }
+                else if (fx == 2 && fy == 2) {
+                    const int c = x >> 1, r = y >> 1, r2 = (y & 1) ? r + 1 : r - 1;
+                    const int cur = 3 * at(c, r) + at(c, r2), side = (x & 1) ? 3 * at(c + 1, r) + at(c + 1, r2) : 3 * at(c - 1, r) + at(c - 1, r2);
+                    v = (3 * cur + side + ((x & 1) ? 7 : 8)) >> 4;
+                } else v = at(x / fx, y / fy); // 1x2 and anything else: replicate
+                full[i][(size_t)y * fw + x] = (uint8_t)v;
+            }
+        }
+        const int fw0 = comp[0].pw * hmax / comp[0].h;
+        for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+            if (ncomp == 1) { img.px[(size_t)y * W + x] = full[0][(size_t)y * fw0 + x]; continue; }
+            double c[3];
+            for (int i = 0; i < 3; ++i) c[i] = full[i][(size_t)y * (comp[i].pw * hmax / comp[i].h) + x];
+            const double r = c[0] + 1.402 * (c[2] - 128.0), g = c[0] - 0.344136 * (c[1] - 128.0) - 0.714136 * (c[2] - 128.0), b = c[0] + 1.772 * (c[1] - 128.0);
+            const double v3[3] = {r, g, b};
+            for (int i = 0; i < 3; ++i) { double q = std::floor(v3[i] + 0.5); img.px[((size_t)y * W + x) * 3 + i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q)); }
+        }
+        img.supported = img.ch == 3; // greyscale = L8: "unsupported image format" for the importer (gltf.rs:91-97)
+        return true;
+    }
+};
+bool decode_image(const std::string &d, Image8 &img, std::string &err) {
+    if (d.size() > 2 && (unsigned char)d[0] == 0xFF && (unsigned char)d[1] == 0xD8) { JpegDec j(d); if (!j.run(img)) { err = j.err; return false; } return true; }
+    return decode_png(d, img, err);
 }
 
 // ---- MIP pyramid (texture.rs:213-236,279-405; same order as textures.py:build_mipmap) ---------------------------
@@ -418,7 +558,7 @@ struct Importer {
             data = buffers[(size_t)bi].substr(o, n);
         }
         Image8 img;
-        if (!decode_png(data, img, err)) return nullptr;
+        if (!decode_image(data, img, err)) return nullptr;
         return &(images[src] = std::move(img));
     }
     bool wrap_mode(const JVal &tex_info, int &wrap) { // wrap_mode_from_gtlf (gltf.rs:30-36) + the wrapS == wrapT asserts

@@ -282,3 +282,58 @@ def test_headless_cli_renders_gltf(cli, ptrs, tmp_path):
     ref = np.clip(srgb * 255.0 + 0.5, 0, 255).astype(np.uint8)
     assert png.shape == (64, 96, 4)
     assert np.abs(png[..., :3].astype(int) - ref.astype(int)).max() <= 2 and (png[..., :3] != ref).mean() < 0.02
+
+
+def _jpeg(arr, **kw):
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format="JPEG", **kw)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("subsampling,smooth,tol", [(0, False, 3), (1, True, 3), (2, True, 3)])
+def test_cpp_jpeg_decoder_close_to_pil(cli, ptrs, tmp_path, subsampling, smooth, tol):
+    """The C++ host's baseline JPEG decoder against PIL's (libjpeg) on the asset's base-colour image: 4:4:4 within
+    IDCT rounding; 4:2:2 and 4:2:0 (triangle chroma upsampling like libjpeg's) on a smooth image likewise."""
+    import base64
+    import json
+    import gltf_fixture as gf
+    path = gf.write_gltf(str(tmp_path), glb=False)
+    doc = json.load(open(path))
+    rng = np.random.default_rng(3)
+    if smooth:
+        yy, xx = np.mgrid[0:32, 0:64]
+        img = np.stack([120 + 100 * np.sin(xx / 9.0), 128 + 90 * np.cos(yy / 7.0), 100 + 2 * xx], axis=-1).clip(0, 255).astype(np.uint8)
+    else:
+        img = rng.integers(0, 255, (32, 64, 3), dtype=np.uint8)  # power-of-two sizes: level 0 is the decoded image itself
+    data = _jpeg(img, quality=92, subsampling=subsampling)
+    doc["images"][1] = {"uri": "data:image/jpeg;base64," + base64.b64encode(data).decode("ascii")}
+    p = str(tmp_path / "jpeg.gltf")
+    json.dump(doc, open(p, "w"))
+    dump = str(tmp_path / "full.dump")
+    subprocess.check_call([cli, p, "--dump-scene-full", dump, "-r", "48x32"])
+    _, _, mats, texs, _ = _read_full_dump(dump, ptrs.abi)
+    cam_p, scene = ptrs.import_scene(p, (48, 32))
+    tid = scene.materials[1]["tex"][0]  # the floor's base colour
+    lc, lp = texs[tid]["levels"], scene.textures[tid]["levels"]
+    assert len(lc) == len(lp) and lc[0].shape == np.asarray(lp[0]).shape
+    # compare in 8-bit sRGB space: undo factor and gamma
+    fac = ptrs.textures.inverse_gamma_correct(np.array([0.8, 0.9, 1.0], np.float32))
+    to8 = lambda v: 255.0 * np.where(v <= 0.0031308, 12.92 * v, 1.055 * np.power(np.maximum(v, 1e-9), 1 / 2.4) - 0.055)
+    a, b = to8(np.asarray(lc[0]) / fac), to8(np.asarray(lp[0]) / fac)
+    assert np.abs(a - b).max() <= tol and np.abs(a - b).mean() < tol / 3
+
+
+def test_cpp_progressive_jpeg_is_refused(cli, tmp_path):
+    import base64
+    import json
+    import gltf_fixture as gf
+    path = gf.write_gltf(str(tmp_path), glb=False)
+    doc = json.load(open(path))
+    img = np.zeros((16, 16, 3), np.uint8)
+    doc["images"][1] = {"uri": "data:image/jpeg;base64," + base64.b64encode(_jpeg(img, progressive=True)).decode("ascii")}
+    p = str(tmp_path / "prog.gltf")
+    json.dump(doc, open(p, "w"))
+    r = subprocess.run([cli, p, "--dump-scene-full", str(tmp_path / "x.dump")], capture_output=True, text=True)
+    assert r.returncode == 1 and "progressive" in r.stderr
