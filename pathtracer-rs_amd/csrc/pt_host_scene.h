@@ -452,6 +452,20 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
     H.use_quad = 4u * H.nodes2.size() + 3u * n_tris > PAIR_FORM_MAX_V4;
     if (const char *f = std::getenv("PTRS_NODE_FORM")) { if (!std::strcmp(f, "quad")) H.use_quad = true; else if (!std::strcmp(f, "pair")) H.use_quad = false; } // test hook
     if (H.use_quad) { H.nodes2.clear(); H.stack_bound = stack_bound4; } else { H.nodes4.clear(); H.stack_bound = stack_bound2; }
+    if (H.use_quad && H.nodes4.size() > QUAD_TOP_NODES) {
+        // breadth-first order for the top of the tree: the first QUAD_TOP_NODES records are the ones every ray starts in,
+        // and the traversal kernels keep them in LDS
+        std::vector<uint32_t> newid(H.nodes4.size(), 0xffffffffu), bfs; bfs.reserve(QUAD_TOP_NODES);
+        bfs.push_back(0);
+        for (size_t h = 0; h < bfs.size() && bfs.size() < QUAD_TOP_NODES; ++h)
+            for (int sl = 0; sl < 4 && bfs.size() < QUAD_TOP_NODES; ++sl) { const uint32_t r = H.nodes4[bfs[h]].ref[sl]; if (r != REF_NONE && !(r & REF_LEAF)) bfs.push_back(r); }
+        uint32_t next = 0;
+        for (uint32_t o : bfs) newid[o] = next++;
+        for (size_t o = 0; o < H.nodes4.size(); ++o) if (newid[o] == 0xffffffffu) newid[o] = next++;
+        std::vector<DNode4> re(H.nodes4.size());
+        for (size_t o = 0; o < H.nodes4.size(); ++o) { DNode4 d = H.nodes4[o]; for (int sl = 0; sl < 4; ++sl) if (d.ref[sl] != REF_NONE && !(d.ref[sl] & REF_LEAF)) d.ref[sl] = newid[d.ref[sl]]; re[newid[o]] = d; }
+        H.nodes4.swap(re);
+    }
     H.tris.resize(order.size());
     for (size_t k = 0; k < order.size(); ++k) {
         const DTriShade &T = H.shade[order[k]]; DTri &t = H.tris[k];

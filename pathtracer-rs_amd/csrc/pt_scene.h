@@ -44,6 +44,7 @@ struct alignas(16) DNode4 {
     uint32_t axes, pad[3];
 };
 static_assert(sizeof(DNode4) == 128, "node4");
+enum : uint32_t { QUAD_TOP_NODES = 85 }; // 1 + 4 + 16 + 64 records of the quad tree's top, kept in LDS by the traversal kernels (10.6 KB)
 enum : uint32_t { PAIR_FORM_MAX_V4 = 1024 }; // largest scene (4 vectors per pair node + 3 per triangle) the kernels stage into LDS
 enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0xffffffffu, REF_FIRST_MASK = 0x07ffffffu, REF_COUNT_SHIFT = 27, REF_MAX_LEAF = 16 };
 

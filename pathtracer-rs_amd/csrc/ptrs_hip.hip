@@ -63,6 +63,20 @@ __device__ inline void block_count(uint32_t *lds_counter, bool pred) {
 // counts[(row * Q_STRIDE + q) * G + b]
 __device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uint32_t G, uint32_t b) { return Q.counts + ((size_t)row * Q_STRIDE + (size_t)q) * G + b; }
 
+// Quad nodes with the top of the tree (the first `ktop` records, breadth-first) in LDS and the rest in global memory.
+// The LDS pointer keeps its address space in the type: with two generic pointers the compiler folds both paths into one
+// generic-address (flat) load, which is slower than either.
+typedef __attribute__((address_space(3))) const v4 lds_v4;
+struct GeomTop {
+    lds_v4 *top; const v4 *nodesv; const DTri *tris; uint32_t ktop;
+    __device__ inline void node8(uint32_t i, v4 *o) const {
+        if (i < ktop) { lds_v4 *q = top + 8u * i; for (int k = 0; k < 8; ++k) { o[k].x = q[k].x; o[k].y = q[k].y; o[k].z = q[k].z; o[k].w = q[k].w; } }
+        else { const v4 *q = nodesv + 8u * i; for (int k = 0; k < 8; ++k) o[k] = q[k]; }
+    }
+    __device__ inline void node(uint32_t, v4 &, v4 &, v4 &, v4 &) const {}
+    __device__ inline void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { const v4 *q = reinterpret_cast<const v4 *>(tris + k); a = q[0]; b = q[1]; c = q[2]; }
+};
+
 // Traversal stack: column `threadIdx.x` of a [D][BLOCK] LDS array of (ref, entry distance) records.
 // OVF: entries beyond D go to this thread's column of a global array (StackSpill), so deep trees keep
 // the LDS footprint -- and with it the occupancy -- of a 16-entry stack.
@@ -201,11 +215,14 @@ __device__ inline uint32_t rf_take(uint32_t *cursor, unsigned long long idle) {
 
 template <int FEAT, int DEPTH, bool OVF, int GEOM>
 __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+    constexpr bool TOP = GEOM == 0 && DEPTH == 8; // quad form with the small stack column: the tree's top lives in LDS
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
-    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
+    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
     __shared__ uint32_t cursor;
-    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
+    GeomLocal GL; const GeomGlobal GG0 = geom_global(sc);
     if (threadIdx.x == 0) cursor = 0;
+    GeomTop GG; GG.top = (lds_v4 *)lds_geom; GG.nodesv = GG0.nodesv; GG.tris = GG0.tris; GG.ktop = 0;
+    if (TOP) { GG.ktop = sc.n_nodes4 < QUAD_TOP_NODES ? sc.n_nodes4 : (uint32_t)QUAD_TOP_NODES; for (uint32_t i = threadIdx.x; i < 8u * GG.ktop; i += BLOCK) lds_geom[i] = GG0.nodesv[i]; }
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
     const uint32_t Gn = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
@@ -250,11 +267,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
 // `hit`, which the shade stage has consumed by now); k_resolve turns them into radiance with full waves.
 template <int FEAT, int DEPTH, bool OVF, int GEOM>
 __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+    constexpr bool TOP = GEOM == 0 && DEPTH == 8;
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
-    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
+    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
     __shared__ uint32_t cursor;
-    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
+    GeomLocal GL; const GeomGlobal GG0 = geom_global(sc);
     if (threadIdx.x == 0) cursor = 0;
+    GeomTop GG; GG.top = (lds_v4 *)lds_geom; GG.nodesv = GG0.nodesv; GG.tris = GG0.tris; GG.ktop = 0;
+    if (TOP) { GG.ktop = sc.n_nodes4 < QUAD_TOP_NODES ? sc.n_nodes4 : (uint32_t)QUAD_TOP_NODES; for (uint32_t i = threadIdx.x; i < 8u * GG.ktop; i += BLOCK) lds_geom[i] = GG0.nodesv[i]; }
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
     const uint32_t Gn = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
@@ -815,11 +835,12 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     sc.texs = (const DTexture *)ps->texs.p; sc.levels = (const DTexLevel *)ps->levels.p; sc.texdata = (const float *)ps->texdata.p; sc.lights = (const DLight *)ps->lights.p;
     sc.distdata = (const float *)ps->distdata.p; sc.inf_lights = (const uint32_t *)ps->inf.p;
     sc.n_nodes = (uint32_t)H.nodes.size(); sc.n_prims = (uint32_t)H.tris.size(); sc.n_lights = (uint32_t)H.lights.size(); sc.n_inf = (uint32_t)H.inf_lights.size();
-    // traversal stack: 8 LDS entries per lane for shallow pair trees (<= 12 levels: the last entries are hardly ever
-    // reached), else 16; what a deeper tree can stack beyond that spills to a global column per resident thread.  PTRS_STACK_LDS=8 forces the small
-    // LDS column (with spill) on any scene -- a test hook for the spill path.
+    // traversal stack: 8 LDS entries per lane; what a deeper tree can stack beyond that spills to a global column per
+    // resident thread.  Quad-form scenes spend the LDS this saves on the top QUAD_TOP_NODES records of the tree (measured
+    // against a 16-entry column without the cache: +2 % on colonnade, +1 % on classroom).  PTRS_STACK_LDS=16 selects that
+    // older layout for quad-form scenes.
     const char *force = getenv("PTRS_STACK_LDS");
-    ps->stack_lds = (!H.use_quad || H.stack_bound <= 12 || (force && atoi(force) == 8)) ? 8u : 16u; // pair form (LDS-staged scenes) only exists with the 8-entry column
+    ps->stack_lds = (H.use_quad && force && atoi(force) == 16) ? 16u : 8u;
     if (const char *gm = getenv("PTRS_GRID_MULT")) { int v = atoi(gm); ps->grid_mult = v < 1 ? 1 : (v > 16 ? 16 : v); }
     if (H.stack_bound > ps->stack_lds) {
         const size_t threads = (size_t)ps->n_cu * 8 * ps->grid_mult * BLOCK;

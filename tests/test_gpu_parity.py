@@ -132,9 +132,12 @@ def test_triangle_soup_matches_oracle(ptrs, orc, scenes):
 
 
 def test_stack_spill_path_matches_oracle(ptrs, orc, scenes, monkeypatch):
-    """PTRS_STACK_LDS=8 forces the 8-entry LDS stack column on a deep tree, so traversal spills the
-    excess entries to the global per-thread columns: results must not change."""
-    monkeypatch.setenv("PTRS_STACK_LDS", "8")
+    """Deep trees spill stack entries beyond the 8-entry LDS column to global per-thread columns (the default for
+    quad-form scenes, with the tree's top records cached in LDS); PTRS_STACK_LDS=16 is the layout without the cache.
+    Results must not depend on it."""
+    cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    monkeypatch.setenv("PTRS_STACK_LDS", "16")
     cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
     rng = np.random.default_rng(5)
