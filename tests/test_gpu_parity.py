@@ -317,3 +317,18 @@ def test_cfg5_band_with_33_bit_sobol_indices(ptrs, orc, scenes):
     assert (b["weight"] > 0).all()
     # 12 800 binary32 additions per pixel in two different orders (the reference's own order depends on tile scheduling)
     assert np.allclose(a["weight"], b["weight"], rtol=1e-4) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-4
+
+
+def test_cfg2_band_at_full_settings(ptrs, orc):
+    """BASELINE configs[1] exactly (Cornell 1024x1024, 256 spp, depth 15) on a 4-row band: ray counts identical to the
+    oracle's over 2.1 M paths, film rows within the tolerance of two summation orders."""
+    cam, scene = ptrs.import_scene(CORNELL, (1024, 1024))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(256, cam.film.get_sample_bounds()), 15)
+    rb, re = 510, 514
+    integ.render(cam, scene, row_begin=rb, row_end=re)
+    st = integ.last_stats
+    film_ref, _, ost = orc.OracleScene(scene).render(cam, orc.make_params(1024, 1024, 256, 15, row_begin=rb, row_end=re), n_threads=16)
+    assert st.samples == ost.samples == 1028 * 8 * 256
+    assert (st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.rays_extension, ost.rays_shadow, ost.rays_mis)
+    a, b = cam.film.pixels[rb:re], film_ref[rb:re]
+    assert np.allclose(a["weight"], b["weight"], rtol=1e-4) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-4
