@@ -88,12 +88,18 @@ inline SampleGrid make_sample_grid(int32_t W, int32_t H, int32_t spp_in) {
     return g;
 }
 
-// FEAT_* bits (pt_texture.h) of a scene: only FEAT_SIMPLE (none) and FEAT_FULL (all) are instantiated
+// FEAT_* bits (pt_texture.h) the shade kernels need for a scene, rounded up to one of the instantiated sets:
+// none, image textures, image textures + environment light, everything
 inline int scene_features(const HostScene &H) {
-    bool any = !H.inf_lights.empty() || H.has_alpha;
-    for (const DTexture &t : H.texs) any = any || t.kind == PTRS_TEX_IMAGE;
-    for (const DMaterial &m : H.mats) any = any || m.kind == PTRS_MAT_NORMAL;
-    return any ? FEAT_FULL : FEAT_SIMPLE;
+    int need = 0;
+    if (!H.inf_lights.empty()) need |= FEAT_INFINITE;
+    if (H.has_alpha) need |= FEAT_ALPHA;
+    for (const DTexture &t : H.texs) if (t.kind == PTRS_TEX_IMAGE) need |= FEAT_IMAGE;
+    for (const DMaterial &m : H.mats) if (m.kind == PTRS_MAT_NORMAL) need |= FEAT_NORMAL;
+    if (need == 0) return FEAT_SIMPLE;
+    if ((need & ~FEAT_IMG) == 0) return FEAT_IMG;
+    if ((need & ~FEAT_IMG_ENV) == 0) return FEAT_IMG_ENV;
+    return FEAT_FULL;
 }
 // Feature set the extension / connection kernels need: textured emission, environment light, alpha masks.
 // (A scene whose only image textures sit on materials can run the lean traversal kernels.)

@@ -9,7 +9,8 @@ namespace pt {
 // Compile-time feature set of a scene (selects kernel instantiations; never changes a value):
 //   FEAT_IMAGE   image textures present (MIP lookups)      FEAT_INFINITE  environment light present
 //   FEAT_NORMAL  NormalMaterial wrappers present            FEAT_ALPHA     alpha-masked meshes present
-enum : int { FEAT_IMAGE = 1, FEAT_INFINITE = 2, FEAT_NORMAL = 4, FEAT_ALPHA = 8, FEAT_SIMPLE = 0, FEAT_FULL = 15 };
+enum : int { FEAT_IMAGE = 1, FEAT_INFINITE = 2, FEAT_NORMAL = 4, FEAT_ALPHA = 8, FEAT_SIMPLE = 0, FEAT_FULL = 15,
+             FEAT_IMG = FEAT_IMAGE, FEAT_IMG_ENV = FEAT_IMAGE | FEAT_INFINITE }; // the two intermediate sets the shade kernels are also built for
 
 PT_HD f3 tex_texel(const DScene &sc, const DTexture &T, uint32_t level, int32_t s, int32_t t) {
     const DTexLevel L = sc.levels[T.first_level + level];

@@ -739,7 +739,11 @@ struct HipBackend {
             default: hipLaunchKernelGGL((k_shade<5, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
         }
     }
-    void shade(uint32_t it, int kind) { t0(1); if (feat == FEAT_FULL) shade_t<FEAT_FULL>(it, kind); else shade_t<FEAT_SIMPLE>(it, kind); t1(); }
+    void shade(uint32_t it, int kind) {
+        t0(1);
+        if (feat == FEAT_SIMPLE) shade_t<FEAT_SIMPLE>(it, kind); else if (feat == FEAT_IMG) shade_t<FEAT_IMG>(it, kind); else if (feat == FEAT_IMG_ENV) shade_t<FEAT_IMG_ENV>(it, kind); else shade_t<FEAT_FULL>(it, kind);
+        t1();
+    }
     void reduce_counts(uint32_t n_rows) { hipLaunchKernelGGL(k_reduce_counts, dim3(n_rows * Q_STRIDE), dim3(BLOCK), 0, stream, (const uint32_t *)Q.counts, G, (uint32_t *)ps->totals[cur].p); }
     uint32_t read_count(uint32_t it, int q) {
         std::vector<uint32_t> seg(G);

@@ -94,7 +94,8 @@ struct HostBackend {
         uint32_t *next = Q.ext[(it + 1) & 1];
         for (uint32_t i = 0, n = cnt(it, Q_MAT0 + kind); i < n; ++i) {
             const uint32_t pid = q[i];
-            const ShadeResult r = feat == FEAT_FULL ? shade_dispatch<FEAT_FULL>(kind, R, S, C, sc, P, pid) : shade_dispatch<FEAT_SIMPLE>(kind, R, S, C, sc, P, pid);
+            const ShadeResult r = feat == FEAT_SIMPLE ? shade_dispatch<FEAT_SIMPLE>(kind, R, S, C, sc, P, pid) : feat == FEAT_IMG ? shade_dispatch<FEAT_IMG>(kind, R, S, C, sc, P, pid)
+                                : feat == FEAT_IMG_ENV ? shade_dispatch<FEAT_IMG_ENV>(kind, R, S, C, sc, P, pid) : shade_dispatch<FEAT_FULL>(kind, R, S, C, sc, P, pid);
             if (r.next) next[cnt(it + 1, Q_EXT)++] = pid;
             if (r.shadow) cnt(it, Q_SHADOW)++;
             if (r.mis) cnt(it, Q_MIS)++;
