@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PTRS_ABI_VERSION 1
+#define PTRS_ABI_VERSION 2
 
 enum {
     PTRS_OK = 0,
@@ -191,9 +191,33 @@ typedef struct PtrsStats {
     uint64_t bvh_nodes;
     uint64_t bvh_max_depth;
     uint64_t device_bytes; /* peak device allocation of the call */
+    /* PTRS_FLAG_TIMING, per kernel class: durations summed over the launches of the call, and the launch counts.
+     * ms_trace = ms_extend + ms_connect; ms_shade = ms_shade_kernels + ms_aux. */
+    double ms_extend;        /* extension-ray traversal kernels (k_extend / k_extend_rf) */
+    double ms_connect;       /* shadow + MIS ray traversal kernels (k_connect / k_connect_rf) */
+    double ms_shade_kernels; /* k_shade<material, features> */
+    double ms_aux;           /* k_generate, k_epilogue, k_resolve */
+    uint64_t extend_launches, connect_launches, shade_launches, aux_launches, film_launches;
+    uint64_t error_flags;    /* PTRS_ERRFLAG_* raised by device code (render returns PTRS_ERR_UNSUPPORTED) */
 } PtrsStats;
 
+enum {
+    PTRS_ERRFLAG_SOBOL_DIM = 1u,  /* a path needed Sobol dimension >= 1024 (the reference panics: sobol.rs:177-183) */
+    PTRS_ERRFLAG_NULL_SKIPS = 2u  /* paths still alive after max_depth + 1 + 64 rounds of null-BSDF skips */
+};
+
 typedef struct PtrsScene PtrsScene;
+
+/* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-4 concurrent
+ * pipeline lanes, default 3), "refill" / "refill_connect" (idle-lane threshold of the lane-refill traversal
+ * kernels, 0 = fused kernels, refill_connect -1 = by scene), "vote" (0/1: phase voting in the traversal
+ * kernels), "stack_lds" (8 or 16 LDS stack entries per lane), "grid_mult", "node_form" (0 auto, 2 force
+ * quad nodes), "workspace_pct" (share of the free device memory the render workspace may take, default
+ * 40).  None of them changes a result bit; they select between equivalent schedules.  Scene-level knobs
+ * (node_form, stack_lds, grid_mult) are read by ptrs_scene_create, the rest by each render call.
+ * Replaces nothing in the reference (its only knobs are the CLI flags of main.rs:36-52). */
+int ptrs_set_option(const char *name, int64_t value);
+int ptrs_get_option(const char *name, int64_t *value);
 
 int ptrs_abi_version(void);
 int ptrs_abi_sizeof(int which); /* sizeof the ABI structs as compiled (binding self-check) */

@@ -70,7 +70,10 @@ class PtrsStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays_extension", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_mis", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("passes", C.c_uint64), ("kernel_launches", C.c_uint64),
                 ("trace_launches", C.c_uint64), ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double),
-                ("ms_film", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_max_depth", C.c_uint64), ("device_bytes", C.c_uint64)]
+                ("ms_film", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_max_depth", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("ms_extend", C.c_double), ("ms_connect", C.c_double), ("ms_shade_kernels", C.c_double), ("ms_aux", C.c_double),
+                ("extend_launches", C.c_uint64), ("connect_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("aux_launches", C.c_uint64),
+                ("film_launches", C.c_uint64), ("error_flags", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

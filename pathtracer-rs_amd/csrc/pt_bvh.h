@@ -123,6 +123,28 @@ PT_HD bool leaf_test(const Geom &G, const DScene &sc, uint32_t leaf, f3 o, const
     return false;
 }
 
+// ONE triangle of a leaf (the phase-voting kernels take a leaf a triangle at a time): tests the first triangle of `leaf`
+// and rewrites `leaf` to the rest of it -- REF_NONE when that was the last one.  Same tests in the same order as leaf_test.
+// Returns true when an any-hit query is done.
+template <bool ALPHA, class Geom>
+PT_HD bool leaf_step(const Geom &G, const DScene &sc, uint32_t &leaf, f3 o, const RayShear &shear, float &t_max, HitRec &out, bool &hit, uint32_t &n_tris, bool any_rt) {
+    const uint32_t first = leaf & REF_FIRST_MASK, rest = (leaf >> REF_COUNT_SHIFT) & 15u; // triangles after this one
+    leaf = rest ? (REF_LEAF | ((rest - 1u) << REF_COUNT_SHIFT) | (first + 1u)) : REF_NONE;
+    v4 ta, tb, tc;
+    G.tri(first, ta, tb, tc);
+    const f3 p0 = mk3(ta.x, ta.y, ta.z), p1 = mk3(ta.w, tb.x, tb.y), p2 = mk3(tb.z, tb.w, tc.x);
+    const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
+    ++n_tris;
+    TriHit h;
+    if (tri_test_s(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
+        if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) return false;
+        if (any_rt) { out.prim = 0; hit = true; return true; }
+        hit = true; t_max = h.t;
+        out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
+    }
+    return false;
+}
+
 template <bool ANY, bool ALPHA, class Stack, class Geom>
 PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_max, Stack &stack, HitRec &out, uint32_t &n_nodes, uint32_t &n_tris) {
     out.prim = -1; out.t = t_max; out.b0 = out.b1 = out.b2 = 0.0f; out.flags = 0;

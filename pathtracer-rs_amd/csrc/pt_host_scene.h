@@ -120,7 +120,8 @@ struct Builder {
 };
 } // namespace hostbvh
 
-inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &err) {
+// node_form: 0 = by size (pair nodes when the tree fits the LDS staging area, quad nodes otherwise), 1 = pair, 2 = quad (test hook)
+inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &err, int node_form = 0) {
     auto bad = [&](const char *m) { err = m; return (int)PTRS_ERR_INVALID; };
     if (d.n_meshes && !d.meshes) return bad("meshes is NULL");
     // ---- textures -------------------------------------------------------------------------------
@@ -159,11 +160,14 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             }
         }
         bool ok = true;
+        for (int k = 0; k < 6; ++k) if (s.tex[k] < -1 || (s.tex[k] >= 0 && (uint32_t)s.tex[k] >= d.n_textures)) return bad("material texture id out of range"); // every slot is -1 or a texture, also the ones its kind ignores
         switch (s.kind) {
             case PTRS_MAT_MATTE: ok = tex_ok(s.tex[0], 3); break;
             case PTRS_MAT_MIRROR: break;
             case PTRS_MAT_GLASS: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 3) && tex_ok(s.tex[2], 1); break;
-            case PTRS_MAT_METAL: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 3) && tex_ok(s.tex[2], 3) && ((tex_ok(s.tex[4], 1) && tex_ok(s.tex[5], 1)) || tex_ok(s.tex[3], 1)); break;
+            case PTRS_MAT_METAL: // u/v roughness: both or neither (pt_material.h prefers them slot by slot); `roughness` is needed for the slots they leave open
+                ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 3) && tex_ok(s.tex[2], 3) && ((tex_ok(s.tex[4], 1) && tex_ok(s.tex[5], 1)) || (s.tex[4] < 0 && s.tex[5] < 0 && tex_ok(s.tex[3], 1))) && (s.tex[3] < 0 || tex_ok(s.tex[3], 1));
+                break;
             case PTRS_MAT_DISNEY: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 1) && tex_ok(s.tex[2], 1) && tex_ok(s.tex[3], 1); break;
             case PTRS_MAT_SUBSTRATE: ok = tex_ok(s.tex[0], 3) && tex_ok(s.tex[1], 3) && tex_ok(s.tex[2], 1) && tex_ok(s.tex[3], 1); break;
             case PTRS_MAT_NORMAL: ok = tex_ok(s.tex[0], 3) && s.inner >= 0 && (uint32_t)s.inner < d.n_materials && (uint32_t)s.inner != i; break;
@@ -450,7 +454,7 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
     }
     // small scenes are walked out of LDS in pair form (cheaper steps when a fetch costs nothing), the rest in quad form
     H.use_quad = 4u * H.nodes2.size() + 3u * n_tris > PAIR_FORM_MAX_V4;
-    if (const char *f = std::getenv("PTRS_NODE_FORM")) { if (!std::strcmp(f, "quad")) H.use_quad = true; else if (!std::strcmp(f, "pair")) H.use_quad = false; } // test hook
+    if (node_form == 2) H.use_quad = true; // (pair form cannot be forced: the kernels only walk it out of LDS)
     if (H.use_quad) { H.nodes2.clear(); H.stack_bound = stack_bound4; } else { H.nodes4.clear(); H.stack_bound = stack_bound2; }
     if (H.use_quad && H.nodes4.size() > QUAD_TOP_NODES) {
         // breadth-first order for the top of the tree: the first QUAD_TOP_NODES records are the ones every ray starts in,

@@ -140,7 +140,14 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     R.counters_on = (prm.flags & PTRS_FLAG_COUNTERS) ? 1u : 0u;
 
     // ---- pass planning ----------------------------------------------------------------------
-    uint64_t capacity = prm.paths_per_pass ? prm.paths_per_pass : (1ull << 27); // up to ~35 GB of path state: HBM (288 GB) is plentiful, launches and tails are not free
+    // Passes run on `be.lanes()` independent pipelines (own path state, queues and stream): while one pass is in the thin
+    // tail of a kernel or waits for its next launch, the other pass's workgroups fill the machine (two concurrent
+    // processes on one MI355X measured +18 % over one).  Film kernels are chained in pass order, so the film is formed
+    // by exactly the same additions as with a single pipeline.
+    const uint32_t n_lanes = std::max(1u, be.lanes());
+    // up to 2^27 paths (~35 GB of path state) per lane: HBM (288 GB) is plentiful, launches and tails are not free.  The back
+    // end bounds it by its share of the memory that is free right now, so the library stays embeddable beside other users.
+    uint64_t capacity = prm.paths_per_pass ? prm.paths_per_pass : std::min<uint64_t>(1ull << 27, be.auto_capacity(n_lanes, sc_host_feat.kinds_present));
     if (capacity < (uint64_t)g.NX) capacity = (uint64_t)g.NX;
     const uint64_t band_rows = (uint64_t)(srow1 - srow0);
     uint64_t rows_per_pass, samples_per_pass;
@@ -156,11 +163,6 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
         const uint64_t n_chunks = (band_rows + rows_max - 1) / rows_max;
         rows_per_pass = (band_rows + n_chunks - 1) / n_chunks;
     }
-    // Passes run on `be.lanes()` independent pipelines (own path state, queues and stream): while one pass is in the thin
-    // tail of a kernel or waits for its next launch, the other pass's workgroups fill the machine (two concurrent
-    // processes on one MI355X measured +18 % over one).  Film kernels are chained in pass order, so the film is formed
-    // by exactly the same additions as with a single pipeline.
-    const uint32_t n_lanes = std::max(1u, be.lanes());
     if (n_lanes > 1 && band_rows * (uint64_t)g.NX <= capacity && !prm.paths_per_pass) { // an even number of equal sample chunks
         const uint64_t spp_max = std::max<uint64_t>(1, std::min<uint64_t>(g.spp, capacity / (band_rows * (uint64_t)g.NX)));
         uint64_t n_chunks = (g.spp + spp_max - 1) / spp_max;

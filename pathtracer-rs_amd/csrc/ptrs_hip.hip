@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -28,6 +29,27 @@ static const unsigned char k_sobol_blob[] = {
 namespace {
 
 thread_local std::string g_err;
+
+// Process-wide tuning knobs (ptrs_set_option).  The library reads no environment variables: an embedding host sets what
+// it needs once; the defaults are the measured best on MI355X.
+struct Options {
+    int lanes = 3;            // concurrent pipeline lanes (own path state, queues and stream each), 1..MAX_LANES
+    int refill = 16;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend
+    int refill_connect = -1;  // the same for the connection kernel; -1 = by scene (quad form: 16, LDS-resident pair form: fused kernel)
+    int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
+    int grid_mult = 1;        // workgroups per pass in units of the resident capacity (8 per CU)
+    int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
+    int vote = 1;             // traversal kernels: each step runs the phase (node visit / triangle test) most lanes of the wave are in
+    int workspace_pct = 40;   // the render workspace (path state + queues of all lanes) may take this share of the device memory that is free at the call
+};
+Options g_opt;
+std::mutex g_opt_mu;
+Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
+struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
+const OptionDesc k_options[] = {
+    {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, 0, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
+    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
+};
 
 #define HIPCHK(expr)                                                                                             \
     do {                                                                                                          \
@@ -213,9 +235,34 @@ __device__ inline uint32_t rf_take(uint32_t *cursor, unsigned long long idle) {
     return base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
 }
 
+// One step of every lane's ray.  vote = 0: the while-while loop (descend to a leaf with all lanes that are still at inner
+// nodes, then that leaf's triangles): a wave waits for its slowest descent and its fattest leaf.  vote = 1: the wave looks at
+// what its lanes need next -- a node visit or a triangle test -- and runs the one more lanes are waiting for, ONE visit or ONE
+// triangle; the others sit the step out.  No lane waits for a straggler, only for its phase to get the majority (which it
+// does: every descending lane reaches a leaf), so at least half of the lanes holding rays work in every step.  Each ray still
+// makes exactly the visits and tests of the while-while loop in the same order: results are identical.
+// (Measured, single lane, VALU lanes active per instruction / ms per frame: see DESIGN.md section 4.)
+template <bool QUAD, bool ALPHA, class Stack, class Geom>
+__device__ inline void rf_step(const Geom &G, const DScene &sc, bool vote, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
+                               Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt) {
+    if (vote) {
+        const bool at_node = r_cur != REF_NONE && !(r_cur & REF_LEAF), at_leaf = r_cur != REF_NONE && (r_cur & REF_LEAF); // lanes without a ray hold REF_NONE
+        if (__popcll(__ballot(at_node)) >= __popcll(__ballot(at_leaf))) {
+            if (at_node) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
+        } else if (at_leaf) {
+            const bool done = leaf_step<ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt);
+            if (done) r_cur = REF_NONE; else if (r_cur == REF_NONE) r_cur = pop_next_ref<false>(stk, r_tmax);
+        }
+        return;
+    }
+    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
+    if (r_cur != REF_NONE) { const bool done = leaf_test<false, ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax); }
+}
+
 template <int FEAT, int DEPTH, bool OVF, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh_vote) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8; // quad form with the small stack column: the tree's top lives in LDS
+    const uint32_t thresh = thresh_vote & 0xffu; const bool vote = (thresh_vote & 0x100u) != 0;
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
     __shared__ uint32_t cursor;
@@ -251,13 +298,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
             if (cursor >= n) dry = true; // lanes that still hold rays learn that the segment is exhausted
         }
         if (!__any(has)) break; // every ray of the segment this wave could get is retired
-        if (GEOM > 0) {
-            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<false, false>(GL, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
-            if (r_cur != REF_NONE) { leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt); r_cur = pop_next_ref<false>(stk, r_tmax); }
-        } else {
-            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<true, false>(GG, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
-            if (r_cur != REF_NONE) { leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt); r_cur = pop_next_ref<false>(stk, r_tmax); }
-        }
+        do { // steps until a lane finishes its ray: only then is there something to retire or refill
+            if (GEOM > 0) rf_step<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false);
+            else rf_step<true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false);
+        } while (vote && !__any(has && r_cur == REF_NONE));
     }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
@@ -266,8 +310,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
 // ray (closest hit) of its record and leaves the answers in the path state (NEE_OCCLUDED in nee2.w, the MIS hit in
 // `hit`, which the shade stage has consumed by now); k_resolve turns them into radiance with full waves.
 template <int FEAT, int DEPTH, bool OVF, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh_vote) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8;
+    const uint32_t thresh = thresh_vote & 0xffu; const bool vote = (thresh_vote & 0x100u) != 0;
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
     __shared__ uint32_t cursor;
@@ -312,13 +357,10 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
             stk.clear(); setup = false;
         }
         if (!__any(has)) break;
-        if (GEOM > 0) {
-            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<false, false>(GL, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
-            if (r_cur != REF_NONE) { const bool done = leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, shadow_phase); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax); }
-        } else {
-            while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<true, false>(GG, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
-            if (r_cur != REF_NONE) { const bool done = leaf_test<false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, shadow_phase); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax); }
-        }
+        do {
+            if (GEOM > 0) rf_step<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase);
+            else rf_step<true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase);
+        } while (vote && !__any(has && r_cur == REF_NONE));
     }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
@@ -597,11 +639,25 @@ struct HipBackend {
     struct Lane { hipStream_t stream; DParams R; DPaths P; DQueues Q; uint32_t G, seg_cap; };
     Lane lane_[MAX_LANES]; uint32_t n_lanes = 3, cur = 0; // measured on Cornell: 1 lane 5376, 2: 6395, 3: 6578, 4: 6618 Mray/s
     hipEvent_t film_prev = nullptr;
-    uint32_t lanes() { if (const char *e = getenv("PTRS_LANES")) { int v = atoi(e); n_lanes = (uint32_t)(v < 1 ? 1 : (v > MAX_LANES ? MAX_LANES : v)); } return n_lanes; } // called before begin()
+    Options opt;
+    uint32_t lanes() { n_lanes = (uint32_t)(opt.lanes < 1 ? 1 : (opt.lanes > MAX_LANES ? MAX_LANES : opt.lanes)); return n_lanes; } // called before begin()
     void select(uint32_t l) {
         if (l == cur) return;
         lane_[cur] = Lane{stream, R, P, Q, G, seg_cap};
         cur = l; stream = lane_[l].stream; R = lane_[l].R; P = lane_[l].P; Q = lane_[l].Q; G = lane_[l].G; seg_cap = lane_[l].seg_cap;
+    }
+    // paths per pass and lane that keep the whole workspace (14 state vectors + 3 + kinds queues per path, all lanes) inside
+    // opt.workspace_pct of the memory that is free now plus what this scene already holds from earlier renders
+    uint64_t auto_capacity(uint32_t lanes_n, const bool *kinds) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 1ull << 27;
+        size_t held = 0;
+        for (auto &l : ps->ws) for (auto &b : l) held += b.bytes;
+        uint32_t nk = 0; for (int k = 0; k < 7; ++k) nk += kinds[k] ? 1u : 0u;
+        const double per_path = 14.0 * 16.0 + (3.0 + nk) * 4.0;
+        const double budget = (double)(fr + held) * (double)opt.workspace_pct / 100.0;
+        const double cap = budget / (per_path * (double)lanes_n);
+        return cap < 65536.0 ? 65536ull : (uint64_t)cap;
     }
     int grid_max = 2048;
     uint32_t refill_connect = 16;
@@ -621,7 +677,9 @@ struct HipBackend {
         if (ev_next == ps->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { rc = PTRS_ERR_DEVICE; return nullptr; } ps->ev_pool.push_back(e); }
         return ps->ev_pool[ev_next++];
     }
-    void t0(int cat) { if (flags & PTRS_FLAG_TIMING) { Span s; s.cat = cat; s.a = ev(); s.b = ev(); if (s.a) (void)hipEventRecord(s.a, stream); spans.push_back(s); } ++launches; if (cat == 0) ++trace_launches; }
+    enum { T_EXTEND = 0, T_AUX = 1, T_FILM = 2, T_CONNECT = 3, T_SHADE = 4, T_NUM = 5 }; // kernel classes of the timing spans
+    uint64_t cat_launches[T_NUM] = {0, 0, 0, 0, 0};
+    void t0(int cat) { if (flags & PTRS_FLAG_TIMING) { Span s; s.cat = cat; s.a = ev(); s.b = ev(); if (s.a) (void)hipEventRecord(s.a, stream); spans.push_back(s); } ++launches; ++cat_launches[cat]; if (cat == T_EXTEND || cat == T_CONNECT) ++trace_launches; }
     void t1() { if (flags & PTRS_FLAG_TIMING) { if (spans.back().b) (void)hipEventRecord(spans.back().b, stream); } }
     int grid_for(uint32_t n) const { uint32_t g = (n + BLOCK - 1) / BLOCK; if (g < 1) g = 1; return (int)(g > (uint32_t)grid_max ? (uint32_t)grid_max : g); }
 
@@ -630,9 +688,8 @@ struct HipBackend {
         grid_max = ps->n_cu * 8 * ps->grid_mult;
         // measured (single lane, Mray/s): Cornell (pair form, LDS) extend-refill 5722 vs none 5560, with connect-refill 5666;
         // colonnade (quad form) none 1517, extend 1698, both 1830
-        refill_connect = sc.n_nodes4 ? 16u : 0u;
-        if (const char *e = getenv("PTRS_REFILL_CONNECT")) { int v = atoi(e); refill_connect = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
-        if (const char *e = getenv("PTRS_REFILL")) { int v = atoi(e); refill = (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }
+        refill_connect = opt.refill_connect >= 0 ? (uint32_t)opt.refill_connect : (sc.n_nodes4 ? 16u : 0u);
+        refill = (uint32_t)opt.refill;
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
@@ -674,7 +731,7 @@ struct HipBackend {
         seg_cap = ((chunks + G - 1) / G) * BLOCK;
         (void)hipMemsetAsync(Q.counts, 0, (size_t)rows * Q_STRIDE * G * 4, stream);
     }
-    void generate() { t0(1); hipLaunchKernelGGL(k_generate, dim3(G), dim3(BLOCK), 0, stream, R, S, C, P, Q, seg_cap); t1(); }
+    void generate() { t0(T_AUX); hipLaunchKernelGGL(k_generate, dim3(G), dim3(BLOCK), 0, stream, R, S, C, P, Q, seg_cap); t1(); }
 
     template <int FEAT> void extend_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
@@ -682,14 +739,14 @@ struct HipBackend {
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill) {
-#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill)
+#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill | (opt.vote ? 0x100u : 0u))
             if (ps->stack_lds == 8) {
                 if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
                 else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
                 else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
             } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
-            t1(); t0(1); // the traversal span ends here: the epilogue is shading-side work
+            t1(); t0(T_AUX); // the traversal span ends here: the epilogue is shading-side work
             hipLaunchKernelGGL((k_epilogue<FEAT>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
             return;
         }
@@ -701,21 +758,21 @@ struct HipBackend {
         } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
     }
-    void extend(uint32_t it) { t0(0); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
+    void extend(uint32_t it) { t0(T_EXTEND); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void connect_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
         StackSpill sp = ps->spill;
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill_connect) {
-#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect)
+#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect | (opt.vote ? 0x100u : 0u))
             if (ps->stack_lds == 8) {
                 if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
                 else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
                 else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
             } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
-            t1(); t0(1);
+            t1(); t0(T_AUX);
             hipLaunchKernelGGL((k_resolve<FEAT>), g, b, 0, stream, sc, P, Q, it, seg_cap);
             return;
         }
@@ -727,7 +784,7 @@ struct HipBackend {
         } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
     }
-    void connect(uint32_t it) { t0(0); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
+    void connect(uint32_t it) { t0(T_CONNECT); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void shade_t(uint32_t it, int kind) {
         dim3 g(G), b(BLOCK);
         switch (kind) {
@@ -740,7 +797,7 @@ struct HipBackend {
         }
     }
     void shade(uint32_t it, int kind) {
-        t0(1);
+        t0(T_SHADE);
         if (feat == FEAT_SIMPLE) shade_t<FEAT_SIMPLE>(it, kind); else if (feat == FEAT_IMG) shade_t<FEAT_IMG>(it, kind); else if (feat == FEAT_IMG_ENV) shade_t<FEAT_IMG_ENV>(it, kind); else shade_t<FEAT_FULL>(it, kind);
         t1();
     }
@@ -761,10 +818,10 @@ struct HipBackend {
         const int32_t tiles_x = (R.W + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
         // film kernels run in pass order whichever lane they are on: the film is one running sum per pixel
         if (n_lanes > 1 && film_prev) (void)hipStreamWaitEvent(stream, film_prev, 0);
-        t0(2); hipLaunchKernelGGL(k_film, dim3((uint32_t)tiles_x * (uint32_t)tiles_y), dim3(BLOCK), 0, stream, R, S, P, (const float *)ps->table.p, film_px, y0, y1, tiles_x); t1();
+        t0(T_FILM); hipLaunchKernelGGL(k_film, dim3((uint32_t)tiles_x * (uint32_t)tiles_y), dim3(BLOCK), 0, stream, R, S, P, (const float *)ps->table.p, film_px, y0, y1, tiles_x); t1();
         if (n_lanes > 1) { film_prev = ps->lane_ev[cur]; (void)hipEventRecord(film_prev, stream); }
     }
-    void export_samples(float *out) { t0(2); hipLaunchKernelGGL(k_export_samples, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, P, out); t1(); }
+    void export_samples(float *out) { t0(T_FILM); hipLaunchKernelGGL(k_export_samples, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, P, out); t1(); }
     void end(PtrsStats &st) {
         for (uint32_t l = 0; l < n_lanes; ++l) { select(l); if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE; }
         select(0);
@@ -776,8 +833,12 @@ struct HipBackend {
         st.kernel_launches = launches; st.trace_launches = trace_launches;
         for (auto &s : spans) {
             float ms = 0.0f;
-            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.cat == 0) st.ms_trace += ms; else if (s.cat == 1) st.ms_shade += ms; else st.ms_film += ms; }
+            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+                if (s.cat == T_EXTEND) st.ms_extend += ms; else if (s.cat == T_CONNECT) st.ms_connect += ms; else if (s.cat == T_SHADE) st.ms_shade_kernels += ms; else if (s.cat == T_AUX) st.ms_aux += ms; else st.ms_film += ms;
+            }
         }
+        st.ms_trace = st.ms_extend + st.ms_connect; st.ms_shade = st.ms_shade_kernels + st.ms_aux;
+        st.extend_launches = cat_launches[T_EXTEND]; st.connect_launches = cat_launches[T_CONNECT]; st.shade_launches = cat_launches[T_SHADE]; st.aux_launches = cat_launches[T_AUX]; st.film_launches = cat_launches[T_FILM];
         size_t bytes = 0;
         for (auto &l : ps->ws) for (auto &b : l) bytes += b.bytes;
         for (auto &b : ps->counts) bytes += b.bytes;
@@ -789,7 +850,7 @@ int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm,
     if (!ps || !cam || !prm || !film_dev) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     HIPCHK(hipSetDevice(ps->device));
     HipBackend be;
-    be.ps = ps; be.stream = stream;
+    be.ps = ps; be.stream = stream; be.opt = options();
     int rc = get_sobol(ps->device, &be.sob);
     if (rc != PTRS_OK) return rc;
     std::string err;
@@ -817,6 +878,27 @@ int ptrs_abi_sizeof(int which) {
     }
 }
 
+int ptrs_set_option(const char *name, int64_t value) {
+    if (!name) { g_err = "null option name"; return PTRS_ERR_INVALID; }
+    for (const OptionDesc &o : k_options)
+        if (!std::strcmp(name, o.name)) {
+            if (value < o.lo || value > o.hi) { g_err = std::string("option ") + name + ": value outside [" + std::to_string(o.lo) + ", " + std::to_string(o.hi) + "]"; return PTRS_ERR_INVALID; }
+            std::lock_guard<std::mutex> lk(g_opt_mu);
+            g_opt.*(o.field) = (int)value;
+            return PTRS_OK;
+        }
+    g_err = std::string("unknown option ") + name;
+    return PTRS_ERR_INVALID;
+}
+
+int ptrs_get_option(const char *name, int64_t *value) {
+    if (!name || !value) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    for (const OptionDesc &o : k_options)
+        if (!std::strcmp(name, o.name)) { std::lock_guard<std::mutex> lk(g_opt_mu); *value = g_opt.*(o.field); return PTRS_OK; }
+    g_err = std::string("unknown option ") + name;
+    return PTRS_ERR_INVALID;
+}
+
 int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out) {
     if (!desc || !out) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     int ndev = 0;
@@ -825,7 +907,8 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     HIPCHK(hipSetDevice(device));
     PtrsScene *ps = new PtrsScene();
     ps->device = device;
-    int rc = build_host_scene(*desc, ps->H, g_err);
+    const Options opt = options();
+    int rc = build_host_scene(*desc, ps->H, g_err, opt.node_form);
     if (rc != PTRS_OK) { delete ps; return rc; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ps->n_cu = prop.multiProcessorCount;
@@ -841,11 +924,10 @@ int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out
     sc.n_nodes = (uint32_t)H.nodes.size(); sc.n_prims = (uint32_t)H.tris.size(); sc.n_lights = (uint32_t)H.lights.size(); sc.n_inf = (uint32_t)H.inf_lights.size();
     // traversal stack: 8 LDS entries per lane; what a deeper tree can stack beyond that spills to a global column per
     // resident thread.  Quad-form scenes spend the LDS this saves on the top QUAD_TOP_NODES records of the tree (measured
-    // against a 16-entry column without the cache: +2 % on colonnade, +1 % on classroom).  PTRS_STACK_LDS=16 selects that
+    // against a 16-entry column without the cache: +2 % on colonnade, +1 % on classroom).  the option stack_lds = 16 selects that
     // older layout for quad-form scenes.
-    const char *force = getenv("PTRS_STACK_LDS");
-    ps->stack_lds = (H.use_quad && force && atoi(force) == 16) ? 16u : 8u;
-    if (const char *gm = getenv("PTRS_GRID_MULT")) { int v = atoi(gm); ps->grid_mult = v < 1 ? 1 : (v > 16 ? 16 : v); }
+    ps->stack_lds = (H.use_quad && opt.stack_lds == 16) ? 16u : 8u;
+    ps->grid_mult = opt.grid_mult;
     if (H.stack_bound > ps->stack_lds) {
         const size_t threads = (size_t)ps->n_cu * 8 * ps->grid_mult * BLOCK;
         ps->spill_lane_elems = threads * (size_t)(H.stack_bound - ps->stack_lds);

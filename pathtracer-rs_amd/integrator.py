@@ -36,20 +36,56 @@ def load_library():
                         "There is no CPU fallback for the render path." % so)
     L = C.CDLL(so)
     L.ptrs_last_error.restype = C.c_char_p
-    if L.ptrs_abi_version() != 1:
+    if L.ptrs_abi_version() != 2:
         raise PtrsError("ABI version mismatch")
     structs = [abi.PtrsTexture, abi.PtrsMaterial, abi.PtrsMesh, abi.PtrsLight, abi.PtrsBvhNode, abi.PtrsSceneDesc, abi.PtrsCamera,
                abi.PtrsRenderParams, abi.PtrsStats, abi.PtrsHit]
     for i, s in enumerate(structs):
         if L.ptrs_abi_sizeof(i) != C.sizeof(s):
             raise PtrsError("ABI struct %s: library %d bytes, binding %d bytes" % (s.__name__, L.ptrs_abi_sizeof(i), C.sizeof(s)))
+    L.ptrs_set_option.argtypes = [C.c_char_p, C.c_int64]
+    L.ptrs_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
     _LIB = L
+    # A/B convenience of this Python host only (the library itself reads no environment): PTRS_OPT_<NAME>=<int>
+    for k, v in os.environ.items():
+        if k.startswith("PTRS_OPT_"):
+            set_option(k[len("PTRS_OPT_"):].lower(), int(v))
     return L
+
+
+def set_option(name, value):
+    """ptrs_set_option: process-wide tuning knob (lanes, refill, refill_connect, vote, stack_lds, grid_mult, node_form,
+    workspace_pct); none of them changes a result."""
+    _check(load_library().ptrs_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int64()
+    _check(load_library().ptrs_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+class options:
+    """Context manager: `with options(lanes=1, refill=0): ...` sets knobs and restores the previous values."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def _check(rc):
     if rc != 0:
-        raise PtrsError("ptrs error %d: %s" % (rc, load_library().ptrs_last_error().decode()))
+        raise PtrsError("ptrs error %d: %s" % (rc, _LIB.ptrs_last_error().decode() if _LIB is not None else "library not loaded"))
 
 
 def round_up_pow2(v):

@@ -2,6 +2,7 @@
 BASELINE.json whose assets (Sponza, Classroom) are not available offline.  Geometry only uses the
 records of include/ptrs.h, so the same description feeds the HIP library and the oracle."""
 import math
+import os
 
 import numpy as np
 
@@ -268,8 +269,11 @@ def colonnade(resolution=(1280, 720), detail=1.0, seed=1, tex_size=1024):
 
 
 # ---- Classroom-class stand-in (BASELINE configs[3]: glass + HDR environment light) -------------------
+TANK_FARM_HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "abandoned_tank_farm_04_1k.hdr")
+
+
 def synthetic_env_map_1k(seed=5):
-    """512x1024 seeded HDR sky (same size class as abandoned_tank_farm_04_1k.hdr, which may not be read)."""
+    """512x1024 seeded HDR sky (same size class as data/abandoned_tank_farm_04_1k.hdr; used where that file is absent)."""
     rows, cols = 512, 1024
     small = synthetic_env_map(64, 128, seed)
     img = np.repeat(np.repeat(small, rows // 64, axis=0), cols // 128, axis=1)
@@ -366,6 +370,8 @@ def classroom(resolution=(1920, 1080), detail=1.0, seed=2, tex_size=512, env=Non
     tris += len(idx)
     cr, sr = math.cos(-math.pi / 2), math.sin(-math.pi / 2)
     l2w = np.array([[1, 0, 0, 0], [0, cr, -sr, 0], [0, sr, cr, 0], [0, 0, 0, 1]], np.float32)
-    tx.add_infinite_light(s, synthetic_env_map_1k() if env is None else env, light_to_world=l2w)
+    if env is None:  # the map BASELINE configs[3] names, shipped as a data fixture; the seeded sky only where it is absent
+        env = tx.read_rgbe(TANK_FARM_HDR) if os.path.exists(TANK_FARM_HDR) else synthetic_env_map_1k()
+    tx.add_infinite_light(s, env, light_to_world=l2w)
     cam = look_at_camera([-7.5, 1.7, -4.6], [3.0, 1.2, 3.5], [0, 1, 0], 60.0, resolution)
     return cam, s

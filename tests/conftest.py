@@ -9,7 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "host_t
     if p not in sys.path:
         sys.path.insert(0, p)
 
-CORNELL = os.path.join(ROOT, "tests", "golden", "cornell-box.xml")
+CORNELL = os.path.join(ROOT, "data", "cornell-box.xml")
 
 
 def pytest_configure(config):

@@ -8,6 +8,9 @@ w.r.t. the reference).  Contents (SURVEY.md section 8c list):
   cornell_hits.npz   ray -> (prim, t, b0, b1, b2) on the Cornell box
   lobes.npz          per-material sample_f / pdf grids
   cornell_film_d4.npz, cornell_film_d15.npz   64x64, 16 spp film (rgb, weight) + ray counts
+  bench_{cornell,colonnade,classroom}_rows.npz   a few film rows of bench.py's three workloads at their FULL settings
+                     (BASELINE configs[1-3]: 1024x1024/256 spp, 1280x720/64 spp, 1920x1080/128 spp, depth 15) + the
+                     band's ray counts: what bench.py's film_check and the full-settings GPU tests compare with
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import importlib
@@ -67,7 +70,7 @@ def main():
         out.update({tag + "_px": px, tag + "_py": py, tag + "_sn": sn, tag + "_dim": dm, tag + "_val": v, tag + "_idx": idx})
     np.savez_compressed(os.path.join(HERE, "sobol_grid.npz"), **out)
 
-    cam, scene = pkg_scene.import_scene(os.path.join(HERE, "cornell-box.xml"), (64, 64))
+    cam, scene = pkg_scene.import_scene(os.path.join(ROOT, "data", "cornell-box.xml"), (64, 64))
     o = orc.OracleScene(scene)
     rays = cornell_rays(cam)
     hits, _ = o.trace_rays(rays)
@@ -83,7 +86,26 @@ def main():
         film, _, st = o.render(cam, orc.make_params(64, 64, 16, depth), n_threads=1)
         np.savez_compressed(os.path.join(HERE, "cornell_film_d%d.npz" % depth), rgb=film["rgb"], weight=film["weight"],
                             rays=np.array([st.rays_extension, st.rays_shadow, st.rays_mis, st.samples], dtype=np.uint64))
+    if "--bench" in sys.argv or "--all" in sys.argv:
+        bench_rows()
     print("golden vectors written to", HERE)
+
+
+BENCH_ROWS = {"cornell": ((1024, 1024), 256, 500, 504), "colonnade": ((1280, 720), 64, 358, 360), "classroom": ((1920, 1080), 128, 540, 542)}
+
+
+def bench_rows():
+    """Film rows [row0, row1) of the three bench workloads at full settings (minutes of CPU time: only with --bench)."""
+    scenes = importlib.import_module("pathtracer-rs_amd.scenes")
+    threads = os.cpu_count() or 1
+    for name, (res, spp, r0, r1) in BENCH_ROWS.items():
+        cam, scene = pkg_scene.import_scene(os.path.join(ROOT, "data", "cornell-box.xml"), res) if name == "cornell" else getattr(scenes, name)(res)
+        o = orc.OracleScene(scene)
+        film, _, st = o.render(cam, orc.make_params(res[0], res[1], spp, 15, row_begin=r0, row_end=r1), n_threads=threads)
+        rows = np.concatenate([film["rgb"], film["weight"][..., None]], axis=-1)[r0:r1].astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, "bench_%s_rows.npz" % name), row0=r0, row1=r1, film=rows,
+                            rays=np.array([st.rays_extension, st.rays_shadow, st.rays_mis, st.samples], dtype=np.uint64))
+        print(name, "rows", r0, r1, "rays", st.rays_extension, st.rays_shadow, st.rays_mis)
 
 
 if __name__ == "__main__":

@@ -68,6 +68,7 @@ struct HostBackend {
         return PTRS_OK;
     }
     uint32_t lanes() const { return 1; }
+    uint64_t auto_capacity(uint32_t, const bool *) const { return 1ull << 27; }
     void select(uint32_t) {}
     void pass_begin(const DParams &R_) { R = R_; std::memset(Q.counts, 0, (size_t)rows * Q_STRIDE * 4); }
     uint32_t &cnt(uint32_t it, int q) { return Q.counts[(size_t)it * Q_STRIDE + q]; }

@@ -131,15 +131,15 @@ def test_triangle_soup_matches_oracle(ptrs, orc, scenes):
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
 
 
-def test_stack_spill_path_matches_oracle(ptrs, orc, scenes, monkeypatch):
+def test_stack_spill_path_matches_oracle(ptrs, orc, scenes):
     """Deep trees spill stack entries beyond the 8-entry LDS column to global per-thread columns (the default for
-    quad-form scenes, with the tree's top records cached in LDS); PTRS_STACK_LDS=16 is the layout without the cache.
-    Results must not depend on it."""
+    quad-form scenes, with the tree's top records cached in LDS); the option stack_lds = 16 is the layout without the
+    cache.  Results must not depend on it."""
     cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
-    monkeypatch.setenv("PTRS_STACK_LDS", "16")
-    cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
-    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    with ptrs.options(stack_lds=16):
+        cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
+        _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
     rng = np.random.default_rng(5)
     o = rng.uniform(-4, 4, (20000, 3)); d = rng.normal(size=(20000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
     rays = np.concatenate([o, d, np.full((20000, 1), np.inf)], axis=1).astype(np.float32)
@@ -148,33 +148,32 @@ def test_stack_spill_path_matches_oracle(ptrs, orc, scenes, monkeypatch):
     assert np.array_equal(hg["prim"], ho["prim"]) and np.array_equal(hg["t"].view(np.uint32), ho["t"].view(np.uint32))
 
 
-def test_fused_extension_kernel_on_a_large_scene(ptrs, orc, scenes, monkeypatch):
-    """PTRS_REFILL / PTRS_REFILL_CONNECT = 0 select the fused k_extend / k_connect instead of the lane-refill kernels
-    (+ k_epilogue / k_resolve); any combination and any idle-lane threshold must give the same samples."""
+def test_traversal_kernel_variants_give_the_same_samples(ptrs, orc, scenes):
+    """The options refill / refill_connect = 0 select the fused k_extend / k_connect instead of the lane-refill kernels
+    (+ k_epilogue / k_resolve), vote = 0 the while-while loop instead of phase voting; any combination and any idle-lane
+    threshold must give the same samples."""
     cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
-    for ext, con in (("0", "0"), ("1", "1"), ("0", "16"), ("64", "0")):
-        monkeypatch.setenv("PTRS_REFILL", ext)
-        monkeypatch.setenv("PTRS_REFILL_CONNECT", con)
-        _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
-    # and on an LDS-resident (pair-form) scene, where connect refill is off by default
+    for ext, con, vote in ((0, 0, 1), (1, 1, 1), (0, 16, 0), (64, 0, 1), (16, 16, 0), (16, 16, 1), (48, 48, 1)):
+        with ptrs.options(refill=ext, refill_connect=con, vote=vote):
+            _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    # and on an LDS-resident (pair-form) scene
     cam, scene = ptrs.import_scene(CORNELL, (48, 48))
-    for ext, con in (("0", "0"), ("16", "16")):
-        monkeypatch.setenv("PTRS_REFILL", ext)
-        monkeypatch.setenv("PTRS_REFILL_CONNECT", con)
-        _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
+    for ext, con, vote in ((0, 0, 1), (16, 16, 0), (16, 16, 1), (16, 0, 1)):
+        with ptrs.options(refill=ext, refill_connect=con, vote=vote):
+            _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
 
 
-def test_pipeline_lanes_do_not_change_the_film(ptrs, monkeypatch):
+def test_pipeline_lanes_do_not_change_the_film(ptrs):
     """Passes overlap on several pipeline lanes (streams with their own path state); the film kernels are chained
     in pass order, so the accumulators must be bit-identical to a single-lane render."""
     films = []
-    for lanes in ("1", "2", "4"):
-        monkeypatch.setenv("PTRS_LANES", lanes)
-        cam, scene = ptrs.import_scene(CORNELL, (96, 80))
-        integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(16, cam.film.get_sample_bounds()), 6, paths_per_pass=30000)  # 6+ passes
-        integ.render(cam, scene)
-        assert integ.last_stats.passes >= 6
-        films.append(cam.film.pixels.copy())
+    for lanes in (1, 2, 4):
+        with ptrs.options(lanes=lanes):
+            cam, scene = ptrs.import_scene(CORNELL, (96, 80))
+            integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(16, cam.film.get_sample_bounds()), 6, paths_per_pass=30000)  # 6+ passes
+            integ.render(cam, scene)
+            assert integ.last_stats.passes >= 6
+            films.append(cam.film.pixels.copy())
     for f in films[1:]:
         assert np.array_equal(f["rgb"].view(np.uint32), films[0]["rgb"].view(np.uint32))
         assert np.array_equal(f["weight"].view(np.uint32), films[0]["weight"].view(np.uint32))

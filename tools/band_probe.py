@@ -13,7 +13,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 pkg = importlib.import_module("pathtracer-rs_amd")
 par = importlib.import_module("pathtracer-rs_amd.parallel")
-cam, scene = pkg.import_scene(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cornell-box.xml"), (1024, 1024))
+cam, scene = pkg.import_scene(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "cornell-box.xml"), (1024, 1024))
 integ = pkg.PathIntegrator(pkg.SamplerBuilder(spp, cam.film.get_sample_bounds()), 15)
 film = torch.zeros((1024, 1024, 4), dtype=torch.float32, device="cuda")
 for _ in range(2):  # warm-up (workspace allocation, clocks)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# tools/prof.sh WORKLOAD TAG [FRAMES] -- one rocprofv3 kernel-trace pass and the PMC passes of `bench.py --profile`
+# (single pipeline lane, FRAMES frames).  Counters are collected in their own runs (no trace domains beside --pmc).
+# Output: gpurun_out/prof_TAG/{kernel_stats.csv,pmc.csv}
+set -e
+W=${1:-cornell}; TAG=${2:-x}; FR=${3:-1}
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+CMD="python3 bench.py --workload $W --steps $FR --profile"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $CMD > "$OUT/kt.log" 2>&1
+cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
+i=0
+for SET in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  echo "pmc pass $i: $SET"
+  rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- $CMD > "$OUT/pmc$i.log" 2>&1
+done
+python3 tools/summarize_pmc.py "$OUT/pmc.csv" "$OUT"/pmc[0-9]
+python3 tools/prof_report.py "$OUT" --json "$OUT/pmc.json" --frames $FR --workload $W --commit "${COMMIT:-?}" > "$OUT/report.txt"
+rm -rf "$OUT"/kt "$OUT"/pmc[0-9]
+echo "done: $OUT"

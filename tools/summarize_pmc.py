@@ -15,8 +15,8 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_]+)", name)
-    return m.group(1) if m else name[:40]
+    m = re.search(r"(k_[a-z_0-9]+(<[^>(]*>)?)", name)  # keeps the template arguments: k_shade<0, 0> and k_shade<4, 3> are different kernels
+    return m.group(1).replace(" ", "") if m else name[:40]
 
 
 def main():
