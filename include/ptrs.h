@@ -199,6 +199,10 @@ typedef struct PtrsStats {
     double ms_aux;           /* k_generate, k_epilogue, k_resolve */
     uint64_t extend_launches, connect_launches, shade_launches, aux_launches, film_launches;
     uint64_t error_flags;    /* PTRS_ERRFLAG_* raised by device code (render returns PTRS_ERR_UNSUPPORTED) */
+    /* PTRS_FLAG_COUNTERS, lane-refill traversal kernels: lane occupancy of the two phases =
+     * node_visits / node_steps_x64 and tris_tested (of these kernels) / tri_steps_x64 */
+    uint64_t node_steps_x64, node_visits, tri_steps_x64;
+    uint64_t debug[12];      /* zero in product builds; diagnostic builds (-DPTRS_STAMPS): wave-clock sums per phase of k_shade */
 } PtrsStats;
 
 enum {
@@ -210,8 +214,8 @@ typedef struct PtrsScene PtrsScene;
 
 /* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-4 concurrent
  * pipeline lanes, default 3), "refill" / "refill_connect" (idle-lane threshold of the lane-refill traversal
- * kernels, 0 = fused kernels, refill_connect -1 = by scene), "vote" (0/1: phase voting in the traversal
- * kernels), "stack_lds" (8 or 16 LDS stack entries per lane), "grid_mult", "node_form" (0 auto, 2 force
+ * kernels, 0 = fused kernels, refill_connect -1 = by scene), "vote" (phase voting in the lane-refill
+ * traversal kernels: 0 off, 1 on, -1 = by scene), "stack_lds" (8 or 16 LDS stack entries per lane), "grid_mult", "shade_lds" (0/1: shade kernels read their small tables from LDS), "node_form" (0 auto, 2 force
  * quad nodes), "workspace_pct" (share of the free device memory the render workspace may take, default
  * 40).  None of them changes a result bit; they select between equivalent schedules.  Scene-level knobs
  * (node_form, stack_lds, grid_mult) are read by ptrs_scene_create, the rest by each render call.

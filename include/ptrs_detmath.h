@@ -98,6 +98,17 @@ PT_HD double ptd_cos(double x) {
     }
 }
 
+/* sin and cos of one argument: the same reduction and polynomials as ptd_sin / ptd_cos, evaluated once -- each result is
+ * bit for bit what the separate functions return */
+PT_HD void ptd_sincos(double x, double *sn, double *cs) {
+    if (ptd_isnan(x) || ptd_isinf(x)) { *sn = ptd_nan(); *cs = ptd_nan(); return; }
+    int q;
+    double r = ptd_reduce_pio2(x, &q);
+    const double ps = ptd_sin_poly(r), pc = ptd_cos_poly(r);
+    *sn = (q & 1) ? pc : ps; if (q & 2) *sn = -*sn;         /* q: 0 sin, 1 cos, 2 -sin, 3 -cos */
+    *cs = (q & 1) ? ps : pc; if (q == 1 || q == 2) *cs = -*cs; /* q: 0 cos, 1 -sin, 2 -cos, 3 sin */
+}
+
 /* ---- log ---------------------------------------------------------------------------------- */
 /* x = m * 2^e, m in [sqrt(1/2), sqrt(2)); returns log(m), writes e.  x must be finite, > 0. */
 PT_HD double ptd_log_mant(double x, int *e_out) {
@@ -232,6 +243,7 @@ PT_HD double ptd_acos(double x) {
 /* ---- binary32 entry points (what the renderer calls) -------------------------------------- */
 PT_HD float pt_sinf(float x) { return (float)ptd_sin((double)x); }
 PT_HD float pt_cosf(float x) { return (float)ptd_cos((double)x); }
+PT_HD void pt_sincosf(float x, float *sn, float *cs) { double s, c; ptd_sincos((double)x, &s, &c); *sn = (float)s; *cs = (float)c; }
 PT_HD float pt_tanf(float x) { return (float)(ptd_sin((double)x) / ptd_cos((double)x)); }
 PT_HD float pt_logf(float x) { return (float)ptd_log((double)x); }
 PT_HD float pt_log2f(float x) { return (float)ptd_log2((double)x); }

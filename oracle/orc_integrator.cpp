@@ -421,6 +421,7 @@ float orc_detmath(int fn, float x, float y) {
     switch (fn) {
         case 0: return pt_sinf(x); case 1: return pt_cosf(x); case 2: return pt_logf(x); case 3: return pt_log2f(x);
         case 4: return pt_expf(x); case 5: return pt_powf(x, y); case 6: return pt_atan2f(x, y); case 7: return pt_acosf(x);
+        case 9: { float sn, cs; pt_sincosf(x, &sn, &cs); return sn; } case 10: { float sn, cs; pt_sincosf(x, &sn, &cs); return cs; }
         default: return pt_tanf(x);
     }
 }

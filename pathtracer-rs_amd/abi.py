@@ -73,7 +73,8 @@ class PtrsStats(C.Structure):
                 ("ms_film", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_max_depth", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("ms_extend", C.c_double), ("ms_connect", C.c_double), ("ms_shade_kernels", C.c_double), ("ms_aux", C.c_double),
                 ("extend_launches", C.c_uint64), ("connect_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("aux_launches", C.c_uint64),
-                ("film_launches", C.c_uint64), ("error_flags", C.c_uint64)]
+                ("film_launches", C.c_uint64), ("error_flags", C.c_uint64), ("node_steps_x64", C.c_uint64), ("node_visits", C.c_uint64),
+                ("tri_steps_x64", C.c_uint64), ("debug", C.c_uint64 * 12)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

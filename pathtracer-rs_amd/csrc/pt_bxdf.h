@@ -40,7 +40,8 @@ PT_HD f2 concentric_disk(f2 u) {
     float theta, r;
     if (fabs_(ox) > fabs_(oy)) { r = ox; theta = PT_PI_4 * (oy / ox); }
     else { r = oy; theta = PT_PI_2 - PT_PI_4 * (ox / oy); }
-    return mk2(r * pt_cosf(theta), r * pt_sinf(theta));
+    float sn, cs; pt_sincosf(theta, &sn, &cs);
+    return mk2(r * cs, r * sn);
 }
 PT_HD f3 cosine_hemisphere(f2 u) {
     f2 d = concentric_disk(u);
@@ -126,7 +127,8 @@ PT_HD void tr_sample11(float ct, float u1, float u2, float &sx, float &sy) {
     if (ct > 0.9999f) {
         float r = sqrt_(u1 / (1.0f - u1));
         float phi = 6.28318530718f * u2;
-        sx = r * pt_cosf(phi); sy = r * pt_sinf(phi);
+        float sn, cs; pt_sincosf(phi, &sn, &cs);
+        sx = r * cs; sy = r * sn;
         return;
     }
     float st = sqrt_(max_(0.0f, 1.0f - ct * ct));
@@ -273,7 +275,7 @@ template <int NL> struct BsdfT {
     Lobe lobe[NL];
 };
 template <int NL> PT_HD void bsdf_init(BsdfT<NL> &b, const Surface &s, float eta) { // bsdf.rs:20-34
-    b.eta = eta; b.ns = s.ns; b.ng = s.n; b.ss = normalize(s.s_dpdu); b.ts = cross(b.ns, b.ss); b.n = 0;
+    b.eta = eta; b.ns = s.ns; b.ng = s.n; b.ss = s.ssn_ok ? s.ssn : normalize(s.s_dpdu); b.ts = cross(b.ns, b.ss); b.n = 0;
 }
 template <int NL> PT_HD f3 to_local(const BsdfT<NL> &b, f3 v) { return mk3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
 template <int NL> PT_HD f3 to_world(const BsdfT<NL> &b, f3 v) {

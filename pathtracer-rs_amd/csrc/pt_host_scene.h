@@ -217,8 +217,13 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             T.material = s.material; T.light = -1; T.alpha_tex = s.alpha_mask_tex;
             T.flags = (s.normal ? TRI_HAS_NORMAL : 0u) | (s.tangent ? TRI_HAS_TANGENT : 0u) | (s.reverse_orientation ? TRI_REVERSE : 0u) | (s.transform_swaps_handedness ? TRI_SWAPS : 0u) |
                       (s.alpha_mask_tex >= 0 ? TRI_HAS_ALPHA : 0u) | ((uint32_t)bucket << TRI_BUCKET_SHIFT);
-            f3 dpdu, dpdv;
-            if (!tri_dpduv(mk3(T.p0[0], T.p0[1], T.p0[2]), mk3(T.p1x, T.p1y, T.p1z), mk3(T.p2x, T.p2y, T.p2z), mk2(T.uv0[0], T.uv0[1]), mk2(T.uv1[0], T.uv1[1]), mk2(T.uv2[0], T.uv2[1]), dpdu, dpdv)) T.flags |= TRI_DEGENERATE;
+            f3 dpdu, dpdv, ng, ssn;
+            const f3 q0 = mk3(T.p0[0], T.p0[1], T.p0[2]), q1 = mk3(T.p1x, T.p1y, T.p1z), q2 = mk3(T.p2x, T.p2y, T.p2z);
+            const f2 t0 = mk2(T.uv0[0], T.uv0[1]), t1 = mk2(T.uv1[0], T.uv1[1]), t2 = mk2(T.uv2[0], T.uv2[1]);
+            if (!tri_dpduv(q0, q1, q2, t0, t1, t2, dpdu, dpdv)) T.flags |= TRI_DEGENERATE;
+            tri_constants(q0, q1, q2, t0, t1, t2, T.flags, ng, ssn, dpdu, dpdv); // what every hit on this triangle would recompute (shape.rs:187-266)
+            T.ng[0] = ng.x; T.ng[1] = ng.y; T.ng[2] = ng.z; T.ssn0 = ssn.x; T.ssn1 = ssn.y; T.ssn2 = ssn.z;
+            T.dpdu0 = dpdu.x; T.dpdu1 = dpdu.y; T.dpdu2 = dpdu.z; T.dpdv[0] = dpdv.x; T.dpdv[1] = dpdv.y; T.dpdv[2] = dpdv.z;
         }
     }
     // ---- lights ---------------------------------------------------------------------------------

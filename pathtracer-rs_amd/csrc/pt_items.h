@@ -63,7 +63,7 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
     P.ray_d[pid] = mkv4(r.d, 0.0f);
     P.beta[pid] = mkv4(splat3(1.0f), 1.0f);
     P.L[pid] = mkv4(splat3(0.0f), 0.0f);
-    u4 st; st.x = (uint32_t)ss.index; st.y = (uint32_t)(ss.index >> 32); st.z = ss.dim | ST_HAS_DIFF; st.w = 0;
+    u4 st; st.x = (uint32_t)ss.index; st.y = (uint32_t)(ss.index >> 32); st.z = ss.dim | ST_HAS_DIFF; st.w = ss.scramble; // the pixel's scramble travels with the path
     P.st[pid] = st;
     P.pfilm[pid] = mkv4(mk3(pf.x, pf.y, 0.0f), 0.0f);
 }
@@ -112,26 +112,84 @@ PT_HD uint32_t hit_pack(int32_t prim, uint32_t flags) {
 PT_HD int32_t hit_prim(uint32_t x) { return x == 0xffffffffu ? -1 : (int32_t)(x & REF_FIRST_MASK); }
 PT_HD uint32_t hit_flags(uint32_t x) { return x == 0xffffffffu ? 0u : ((((x >> 27) & 7u) << TRI_BUCKET_SHIFT) | (((x >> 30) & 1u) ? (uint32_t)TRI_IS_LIGHT : 0u)); }
 
-struct ShadeResult { bool next; bool nee; bool shadow; bool mis; };
+// In-kernel stamps (diagnostic builds only, -DPTRS_STAMPS, tools/ablate.sh): wave-clock deltas between the phases of
+// shade_item, summed per phase into Q.stats[CNT_STAMP0 + k].  `dep` names values that must exist before the stamp is
+// taken, so the wait for their loads falls into the phase before it.  The product build compiles none of this.
+#if defined(PTRS_STAMPS) && defined(__HIPCC__)
+#define PT_STAMP_PARAMS , unsigned long long *stamp_acc, unsigned long long &stamp_last
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_STAMP(k, dep) { unsigned long long t_; const uint32_t d_ = (dep); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(d_) : "memory"); stamp_acc[k] += t_ - stamp_last; stamp_last = t_; }
+#else
+#define PT_STAMP(k, dep)
+#endif
+#else
+#define PT_STAMP_PARAMS
+#define PT_STAMP(k, dep)
+#endif
 
-template <int MAT, int FEAT>
-PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid) {
-    ShadeResult out; out.next = false; out.nee = false; out.shadow = false; out.mis = false;
-    const f3 ro = xyz(P.ray_o[pid]);
-    const f3 rd = xyz(P.ray_d[pid]);
-    v4 bv = P.beta[pid];
+// Where shade_item finds its read-only tables.  This one reads everything from global memory (host twin, and the base of
+// the gfx950 context in ptrs_hip.hip, which serves the light records, small scenes' triangle records and the Sobol' tables
+// of the current round out of LDS: the shade kernels are bound by the number of vector-memory instructions in flight, not
+// by bytes).
+struct ShadeCtx {
+    PT_MEM TriRegs tri(const DScene &sc, int32_t prim, bool want_dp) const { return load_tri_regs(sc.shade + prim, want_dp); }
+    PT_MEM void light(const DScene &sc, uint32_t li, DLight &out) const { out = sc.lights[li]; }
+    template <int N> PT_MEM void sobol(const DSampler &S, uint64_t index, const uint32_t (&dim)[N], uint32_t scramble, float (&out)[N]) const { sobol_batch<N>(S, index, dim, scramble, out); }
+    PT_MEM void before_stores() const {}
+};
+
+struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; }; // err_dim: a Sobol dimension >= 1024 was drawn (the reference panics, sobol.rs:177-183)
+
+// What a shading vertex reads of its path: five 16-byte vectors out of HBM (nothing else of a path is cache-resident: a
+// pass holds tens of GB of path state).  The gfx950 shade kernel fetches the NEXT item's PathIn while it shades the
+// current one (k_shade), which hides the one HBM round trip of the stage.
+struct PathIn { v4 ro, rd, beta; u4 st, hit; };
+PT_HD PathIn load_path_in(const DPaths &P, uint32_t pid) { PathIn p; p.ro = P.ray_o[pid]; p.rd = P.ray_d[pid]; p.beta = P.beta[pid]; p.st = P.st[pid]; p.hit = P.hit[pid]; return p; }
+
+template <int MAT, int FEAT, class CTX = ShadeCtx>
+PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid, const PathIn &in, const CTX &X PT_STAMP_PARAMS) {
+    ShadeResult out; out.next = false; out.nee = false; out.shadow = false; out.mis = false; out.err_dim = false;
+    // ---- memory round trip 1: the path's state (already requested by the caller) ------------------------------------
+    const v4 rov = in.ro, rdv = in.rd;
+    v4 bv = in.beta;
+    u4 stv = in.st;
+    const u4 h = in.hit;
+    const f3 ro = xyz(rov), rd = xyz(rdv);
     f3 beta = xyz(bv);
     float eta_scale = bv.w;
-    u4 stv = P.st[pid];
-    u4 h = P.hit[pid];
     const int32_t prim = hit_prim(h.x);
-    const TriRegs T = load_tri_regs(sc.shade + prim);
     int32_t bounces = st_bounces(stv.z);
-    PathCoord c = path_coord(R, S, pid);
-    SamplerState ss;
-    ss.index = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
-    ss.dim = stv.z & ST_DIM_MASK; ss.scramble = pixel_scramble(c.px, c.py); ss.px = c.px; ss.py = c.py;
-
+    const uint64_t index = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
+    const uint32_t dim0 = stv.z & ST_DIM_MASK, scramble = stv.w;
+    PT_STAMP(0, h.x + stv.z + f2u(rov.x) + f2u(rdv.x) + f2u(bv.x))
+    // ---- round trip 2: the triangle's shading record and ALL Sobol' table entries this vertex can need -----------
+    // Whether the vertex does next-event estimation is a property of the material kind, except for a Substrate without
+    // lobes (Q20) and a glass that yields no BSDF (Q17): the draws below assume the kind's usual answer; the rare other
+    // case draws again further down (same function of (index, dimension), so the same values).
+    constexpr bool NEE_KIND = MAT != PTRS_MAT_MIRROR && MAT != PTRS_MAT_GLASS;
+    const bool nee_guess = NEE_KIND && sc.n_lights > 0;
+    const TriRegs T = X.tri(sc, prim, (FEAT & FEAT_IMAGE) != 0);
+    VertexDims V = vertex_dims(dim0, nee_guess);
+    float u_nee[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, u_tail[3];
+    {
+        const uint32_t dt[3] = {V.cont[0], V.cont[1], V.rr};
+        if (nee_guess) {
+            const uint32_t dn[8] = {V.nee[0], V.nee[1], V.nee[2], V.nee[3], V.nee[4], dt[0], dt[1], dt[2]};
+            float u8[8];
+            X.template sobol<8>(S, index, dn, scramble, u8);
+            for (int k = 0; k < 5; ++k) u_nee[k] = u8[k];
+            u_tail[0] = u8[5]; u_tail[1] = u8[6]; u_tail[2] = u8[7];
+        } else X.template sobol<3>(S, index, dt, scramble, u_tail);
+    }
+    PT_STAMP(1, f2u(T.ng.x) + f2u(T.p0.x) + f2u(T.n0.x) + f2u(T.uv0.x) + f2u(u_tail[2]) + f2u(u_nee[4]) + T.flags)
+    // ---- round trip 3: the light record (its index is the fifth draw) and the material record ---------------------
+    uint32_t li = 0;
+    if (nee_guess) {
+        const float fl = floor_(u_nee[4] * (float)sc.n_lights);
+        li = fl > 0.0f ? (uint32_t)fl : 0u;
+        if (li > sc.n_lights - 1u) li = sc.n_lights - 1u;
+    }
+    PT_STAMP(2, li)
     const f3 wo = -rd;
     Surface s = tri_surface(T, prim, u2f(h.y), u2f(h.z), u2f(h.w), wo);
     // Only the camera ray carries differentials (Q9) and only image-texture lookups read them
@@ -141,28 +199,36 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         CamRay cr = camera_ray(C, mk2(pf.x, pf.y), R.inv_sqrt_spp);
         surface_differentials(s, ro, cr.rx_d, ro, cr.ry_d);
     }
+    // Everything this vertex writes is collected in registers and stored at the very end, behind X.before_stores(): the
+    // gfx950 kernel waits there for the NEXT item's prefetched state (vmcnt counts loads and stores alike, so waiting
+    // anywhere after a store would also wait for that store).
+    v4 w_sh_o, w_sh_d, w_mis_o, w_mis_d, w_nee0, w_nee1, w_ro, w_rd, w_beta; u4 w_nee2, w_st;
+    bool w_skip = false; // null-BSDF skip: only the ray origin and the state word change
+    w_sh_o = w_sh_d = w_mis_o = w_mis_d = w_nee0 = w_nee1 = w_ro = w_rd = w_beta = mkv4(splat3(0.0f), 0.0f); w_nee2.x = w_nee2.y = w_nee2.z = w_nee2.w = 0; w_st = stv;
     BsdfT<MatLobes<MAT>::N> bsdf;
     if (!make_bsdf<MAT, FEAT>(sc, T.material, s, bsdf)) { // integrator.rs:434-439 (Q7)
         f3 o2 = spawn_origin(s.p, s.p_error, s.n, rd);
-        P.ray_o[pid] = mkv4(o2, PT_INF);
-        stv.z = st_pack(ss.dim, stv.z & ST_SPECULAR, bounces - 1);
-        P.st[pid] = stv;
-        out.next = true;
-        return out;
-    }
-
+        w_ro = mkv4(o2, PT_INF);
+        w_st.z = st_pack(dim0, stv.z & ST_SPECULAR, bounces - 1);
+        w_skip = true;
+    } else {
+    PT_STAMP(3, f2u(bsdf.ss.x) + f2u(bsdf.ts.y) + f2u(s.p.x) + f2u(s.p_error.x))
     // ---- direct lighting: uniform_sample_one_light + estimate_direct up to the scene queries ----
     const uint32_t NS = BSDF_ALL & ~BSDF_SPECULAR;
-    if (bsdf_num(bsdf, NS) > 0 && sc.n_lights > 0) {
-        f2 u_light = get_2d(S, ss);
-        f2 u_scat = get_2d(S, ss);
-        float fl = floor_(get_1d(S, ss) * (float)sc.n_lights);
-        uint32_t li = fl > 0.0f ? (uint32_t)fl : 0u;
-        if (li > sc.n_lights - 1u) li = sc.n_lights - 1u;
-        const DLight &Lt = sc.lights[li];
+    const bool do_nee = bsdf_num(bsdf, NS) > 0 && sc.n_lights > 0;
+    if (do_nee != nee_guess) { // only a lobeless Substrate gets here (do_nee false, nee_guess true): its draws start at dim0
+        V = vertex_dims(dim0, false);
+        const uint32_t dt[3] = {V.cont[0], V.cont[1], V.rr};
+        X.template sobol<3>(S, index, dt, scramble, u_tail);
+    }
+    if (do_nee) {
+        DLight Lt; // a register copy of the light's record (LDS-resident for scenes with few lights): the fields its kind reads are fetched together
+        X.light(sc, li, Lt);
+        const f2 u_light = mk2(u_nee[0], u_nee[1]), u_scat = mk2(u_nee[2], u_nee[3]);
         const bool delta = light_is_delta(Lt);
         LightSample ls;
         light_sample_li<FEAT>(sc, Lt, s.p, s.p_error, s.n, u_light, ls);
+        PT_STAMP(4, f2u(ls.pdf) + f2u(ls.wi.x) + f2u(ls.li.x) + f2u(ls.p1.x))
         f3 A = splat3(0.0f);
         float spdf = 0.0f;
         f3 wi = ls.wi;
@@ -173,12 +239,13 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
                 // VisibilityTester::unoccluded -> spawn_ray_to_it (interaction.rs:50-60, Q13)
                 f3 origin = offset_ray_origin(s.p, s.p_error, s.n, ls.p1 - s.p);
                 f3 target = offset_ray_origin(ls.p1, ls.p1_err, ls.p1_n, origin - ls.p1);
-                P.sh_o[pid] = mkv4(origin, 1.0f - 0.0001f);
-                P.sh_d[pid] = mkv4(target - origin, 0.0f);
+                w_sh_o = mkv4(origin, 1.0f - 0.0001f);
+                w_sh_d = mkv4(target - origin, 0.0f);
                 A = delta ? f * ls.li / ls.pdf : f * ls.li * power_heuristic(ls.pdf, spdf) / ls.pdf;
                 out.shadow = true;
             }
         }
+        PT_STAMP(5, f2u(A.x) + f2u(spdf) + (out.shadow ? 1u : 0u))
         f3 fB = splat3(0.0f); float wB = 1.0f;
         if (!delta) {
             uint32_t sampled = BSDF_ALL;
@@ -192,49 +259,68 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
                     else wB = power_heuristic(spdf, lpdf);
                 }
                 if (ok) {
-                    P.mis_o[pid] = mkv4(spawn_origin(s.p, s.p_error, s.n, wi), PT_INF);
-                    P.mis_d[pid] = mkv4(wi, 0.0f);
+                    w_mis_o = mkv4(spawn_origin(s.p, s.p_error, s.n, wi), PT_INF);
+                    w_mis_d = mkv4(wi, 0.0f);
                     out.mis = true;
                 }
             }
         }
+        PT_STAMP(6, f2u(fB.x) + f2u(wB) + (out.mis ? 1u : 0u))
         if (out.shadow || out.mis) {
             out.nee = true;
-            P.nee0[pid] = mkv4(A, wB);
-            P.nee1[pid] = mkv4(fB, spdf);
-            u4 n2; n2.x = f2u(beta.x); n2.y = f2u(beta.y); n2.z = f2u(beta.z);
-            n2.w = li | ((out.shadow ? NEE_SHADOW : 0u) | (out.mis ? NEE_MIS : 0u)) << 24;
-            P.nee2[pid] = n2;
+            w_nee0 = mkv4(A, wB);
+            w_nee1 = mkv4(fB, spdf);
+            w_nee2.x = f2u(beta.x); w_nee2.y = f2u(beta.y); w_nee2.z = f2u(beta.z);
+            w_nee2.w = li | ((out.shadow ? NEE_SHADOW : 0u) | (out.mis ? NEE_MIS : 0u)) << 24;
         }
     }
 
     // ---- continuation: integrator.rs:449-499 ---------------------------------------------------
+    uint32_t dim = V.after_cont;
     f3 wi = splat3(0.0f);
     float pdf = 0.0f; uint32_t flags = 0;
-    f3 f = bsdf_sample_f(bsdf, wo, wi, get_2d(S, ss), pdf, BSDF_ALL, flags);
-    if (is_black(f) || pdf == 0.0f) return out;
-    beta = beta * (f * fabs_(dot(wi, s.ns)) / pdf);
-    const bool spec = (flags & BSDF_SPECULAR) != 0;
-    if (spec && (flags & BSDF_TRANSMISSION)) {
-        float eta = bsdf.eta;
-        eta_scale *= dot(wo, s.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
-    }
-    f3 o2 = spawn_origin(s.p, s.p_error, s.n, wi);
-    if (R.rr_enable) {
-        float mx = max_comp(beta * eta_scale);
-        if (mx < R.rr_threshold && bounces > R.rr_start_depth) {
-            float q = max_(0.05f, 1.0f - mx);
-            if (get_1d(S, ss) < q) return out;
-            beta = beta / (1.0f - q);
+    f3 f = bsdf_sample_f(bsdf, wo, wi, mk2(u_tail[0], u_tail[1]), pdf, BSDF_ALL, flags);
+    bool alive = true;
+    if (dim > 1024u) { out.err_dim = true; alive = false; } // a dimension >= 1024 was drawn: the reference panics here
+    if (is_black(f) || pdf == 0.0f) alive = false;
+    if (alive) {
+        beta = beta * (f * fabs_(dot(wi, s.ns)) / pdf);
+        const bool spec = (flags & BSDF_SPECULAR) != 0;
+        if (spec && (flags & BSDF_TRANSMISSION)) {
+            float eta = bsdf.eta;
+            eta_scale *= dot(wo, s.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
+        }
+        f3 o2 = spawn_origin(s.p, s.p_error, s.n, wi);
+        if (R.rr_enable) {
+            float mx = max_comp(beta * eta_scale);
+            if (mx < R.rr_threshold && bounces > R.rr_start_depth) {
+                float q = max_(0.05f, 1.0f - mx);
+                dim += 1; // get_1d
+                if (dim > 1024u) { out.err_dim = true; alive = false; }
+                else if (u_tail[2] < q) alive = false;
+                else beta = beta / (1.0f - q);
+            }
+        }
+        if (alive) {
+            PT_STAMP(7, f2u(beta.x) + f2u(o2.x) + f2u(wi.x))
+            bounces += 1;
+            w_ro = mkv4(o2, PT_INF);
+            w_rd = mkv4(wi, 0.0f);
+            w_beta = mkv4(beta, eta_scale);
+            w_st.z = st_pack(dim, spec ? ST_SPECULAR : 0u, bounces);
+            out.next = true;
         }
     }
-    bounces += 1;
-    P.ray_o[pid] = mkv4(o2, PT_INF);
-    P.ray_d[pid] = mkv4(wi, 0.0f);
-    P.beta[pid] = mkv4(beta, eta_scale);
-    stv.z = st_pack(ss.dim, spec ? ST_SPECULAR : 0u, bounces);
-    P.st[pid] = stv;
-    out.next = true;
+    if (out.err_dim) { out.nee = false; out.shadow = false; out.mis = false; out.next = false; }
+    }
+    // ---- the vertex's stores ------------------------------------------------------------------------------------------
+    X.before_stores();
+    if (out.shadow) { P.sh_o[pid] = w_sh_o; P.sh_d[pid] = w_sh_d; }
+    if (out.mis) { P.mis_o[pid] = w_mis_o; P.mis_d[pid] = w_mis_d; }
+    if (out.nee) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; }
+    if (w_skip) { P.ray_o[pid] = w_ro; P.st[pid] = w_st; out.next = true; }
+    else if (out.next) { P.ray_o[pid] = w_ro; P.ray_d[pid] = w_rd; P.beta[pid] = w_beta; P.st[pid] = w_st; }
+    PT_STAMP(8, 0u)
     return out;
 }
 
@@ -290,12 +376,12 @@ PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32
 template <int FEAT>
 PT_HD ShadeResult shade_dispatch(int bucket, const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid) {
     switch (bucket) {
-        case 0: return shade_item<0, FEAT>(R, S, C, sc, P, pid);
-        case 1: return shade_item<1, FEAT>(R, S, C, sc, P, pid);
-        case 2: return shade_item<2, FEAT>(R, S, C, sc, P, pid);
-        case 3: return shade_item<3, FEAT>(R, S, C, sc, P, pid);
-        case 4: return shade_item<4, FEAT>(R, S, C, sc, P, pid);
-        default: return shade_item<5, FEAT>(R, S, C, sc, P, pid);
+        case 0: return shade_item<0, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
+        case 1: return shade_item<1, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
+        case 2: return shade_item<2, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
+        case 3: return shade_item<3, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
+        case 4: return shade_item<4, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
+        default: return shade_item<5, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
     }
 }
 

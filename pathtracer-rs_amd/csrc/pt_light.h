@@ -40,8 +40,7 @@ PT_HD void tri_sample(const TriRegs &T, f2 u, f3 &p, f3 &n, f3 &perr, f2 &uv, co
 PT_HD void tri_point_normal(const TriRegs &T, float b0, float b1, float b2, f3 &p, f3 &n) {
     f3 p0 = T.p0, p1 = T.p1, p2 = T.p2;
     p = b0 * p0 + b1 * p1 + b2 * p2;
-    n = normalize(cross(p0 - p2, p1 - p2));
-    if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) n = -n;
+    n = T.ng;
     if (T.flags & (TRI_HAS_NORMAL | TRI_HAS_TANGENT)) {
         f3 ns;
         if (T.flags & TRI_HAS_NORMAL) {
@@ -51,9 +50,8 @@ PT_HD void tri_point_normal(const TriRegs &T, float b0, float b1, float b2, f3 &
         f3 ss;
         if (T.flags & TRI_HAS_TANGENT) {
             ss = b0 * T.s0 + b1 * T.s1 + b2 * T.s2;
-            if (len2(ss) > 0.0f) ss = normalize(ss);
-            else { f3 du, dv; tri_dpduv(p0, p1, p2, T.uv0, T.uv1, T.uv2, du, dv); ss = normalize(du); }
-        } else { f3 du, dv; tri_dpduv(p0, p1, p2, T.uv0, T.uv1, T.uv2, du, dv); ss = normalize(du); }
+            ss = len2(ss) > 0.0f ? normalize(ss) : T.ssn;
+        } else ss = T.ssn;
         f3 ts = cross(ss, ns);
         if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
         else coordinate_system(ns, ss, ts);
@@ -130,7 +128,7 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
     float map_pdf = pdf_u * pdf_v;
     if (map_pdf == 0.0f) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; }
     float theta = d1 * PT_PI, phi = d0 * 2.0f * PT_PI;
-    float ct = pt_cosf(theta), st = pt_sinf(theta), sp = pt_sinf(phi), cp = pt_cosf(phi);
+    float ct, st, sp, cp; pt_sincosf(theta, &st, &ct); pt_sincosf(phi, &sp, &cp);
     o.wi = xform_vec(L.l2w, mk3(st * cp, st * sp, ct));
     o.pdf = st == 0.0f ? 0.0f : map_pdf / (2.0f * PT_PI * PT_PI * st);
     o.p1 = ref_p + o.wi * (2.0f * L.world_radius);

@@ -28,7 +28,7 @@ PT_HD void normal_mapping(const DScene &sc, int32_t tex, Surface &s) { // mod.rs
     f3 ts = cross(ss, ns);
     if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
     else coordinate_system(ns, ss, ts);
-    s.ns = ns; s.s_dpdu = ss; s.s_dpdv = ts;
+    s.ns = ns; s.s_dpdu = ss; s.s_dpdv = ts; s.ssn_ok = false;
 }
 
 // texture slot k of material m: the folded constant when the texture is a ConstantTexture

@@ -126,7 +126,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     const int32_t srow0 = std::max(rb, 0), srow1 = std::min(re + 4, g.NY);
 
     DSampler S;
-    S.matrices = be.sobol_matrices(); S.bytetab = be.sobol_bytetab(); S.vdc = be.sobol_vdc(g.log2_res - 1); S.vdc_inv = be.sobol_vdc_inv(g.log2_res - 1);
+    S.matrices = be.sobol_matrices(); S.bytetab = be.sobol_bytetab(); S.nibtab = be.sobol_nibtab(); S.vdc = be.sobol_vdc(g.log2_res - 1); S.vdc_inv = be.sobol_vdc_inv(g.log2_res - 1);
     S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
     DCamera C;
     std::memcpy(C.rot, cam.rot, 16); std::memcpy(C.trans, cam.trans, 12);
@@ -198,6 +198,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
         pd.active = false;
     };
     uint32_t pass_no = 0;
+    bool null_skip_overrun = false;
     for (int32_t r0 = srow0; r0 < srow1; r0 += (int32_t)rows_per_pass) {
         const int32_t r1 = std::min<int32_t>(srow1, r0 + (int32_t)rows_per_pass);
         for (uint32_t s0 = 0; s0 < g.spp; s0 += (uint32_t)samples_per_pass, ++pass_no) {
@@ -218,8 +219,10 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             for (; it < fixed_iters; ++it) round(it);
             // A path can outlive max_depth+1 rounds only through null-BSDF skips (`bounces -= 1`,
             // integrator.rs:434-439), which only glass can produce: poll the queue in that case.
-            if (kinds_present[PTRS_MAT_GLASS])
+            if (kinds_present[PTRS_MAT_GLASS]) {
                 while (it < max_iters && be.read_count(it, Q_EXT) != 0) { round(it); ++it; }
+                if (it == max_iters && be.read_count(it, Q_EXT) != 0) null_skip_overrun = true; // paths still alive: never dropped silently
+            }
             // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
             const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);
             if (y1 > y0) be.film(film, y0, y1); // ordered after the previous pass's film kernel, whichever lane ran it
@@ -229,9 +232,12 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     }
     for (uint32_t l = 0; l < n_lanes; ++l) finish(l);
     be.end(st);
+    if (null_skip_overrun) st.error_flags |= PTRS_ERRFLAG_NULL_SKIPS;
     st.bvh_nodes = sc.n_nodes; st.bvh_max_depth = bvh_depth;
     st.ms_total = std::chrono::duration<double, std::milli>(clock::now() - t_begin).count();
     if (stats) *stats = st;
+    if (st.error_flags & PTRS_ERRFLAG_SOBOL_DIM) { err = "sobol sampler can only sample up to 1024 dimensions (sobol.rs:177-183): max_depth is too large for this scene"; return PTRS_ERR_UNSUPPORTED; }
+    if (st.error_flags & PTRS_ERRFLAG_NULL_SKIPS) { err = "paths still alive after max_depth + 65 rounds of null-BSDF skips (integrator.rs:434-439)"; return PTRS_ERR_UNSUPPORTED; }
     return PTRS_OK;
 }
 

@@ -58,9 +58,11 @@ struct alignas(16) DTri { // leaf order; read by traversal as 3 x 16 B
     float p2z; uint32_t prim; uint32_t flags; int32_t alpha_tex;
 };
 
-// Per-triangle shading record, indexed by global triangle id (mesh-major).  Ten 16-byte vectors so
-// the shade stage fetches it with wide loads (v0-v2 always, v3-v6 for normals/uvs, v7-v9 only when
-// the mesh has tangents).
+// Per-triangle shading record, indexed by global triangle id (mesh-major).  Thirteen 16-byte vectors so
+// the shade stage fetches it with wide loads (v0-v6 always, v7-v9 only when the mesh has tangents, v10-v11 always,
+// v12 only where texture differentials are computed).  v10-v12 hold what Triangle::intersect (shape.rs:187-266)
+// recomputes at every hit although it depends on the triangle alone -- the geometric normal, dp/du, dp/dv and
+// normalize(dp/du) -- evaluated once on the host with the same binary32 operations (pt_tri.h).
 struct alignas(16) DTriShade {
     float p0[3]; float p1x;                                   // v0
     float p1y, p1z, p2x, p2y;                                 // v1
@@ -72,10 +74,13 @@ struct alignas(16) DTriShade {
     float s0[3]; float s1x;                                   // v7
     float s1y, s1z, s2x, s2y;                                 // v8
     float s2z; uint32_t pad[3];                               // v9
+    float ng[3]; float ssn0;                                  // v10 ng = normalize(cross(p0-p2, p1-p2)), flipped for reverse_orientation ^ swaps_handedness
+    float ssn1, ssn2, dpdu0, dpdu1;                           // v11 ssn = normalize(dpdu)
+    float dpdu2; float dpdv[3];                               // v12
 };
 static_assert(sizeof(DNode) == 32, "node");
 static_assert(sizeof(DTri) == 48, "tri");
-static_assert(sizeof(DTriShade) == 160, "trishade");
+static_assert(sizeof(DTriShade) == 208, "trishade");
 
 // tex[k] >= 0: texture id.  When that texture is a ConstantTexture its value is also folded into
 // cval[k] and bit k of const_mask is set, which saves the dependent texture-record fetch.
@@ -126,11 +131,12 @@ struct DScene {
     uint32_t n_nodes, n_prims, n_lights, n_inf;
 };
 
-enum { SOBOL_TAB_DIMS = 256 };
+enum { SOBOL_TAB_DIMS = 256, SOBOL_NIBBLES = 13 }; // 13 nibbles hold the 52 matrix columns
 
 struct DSampler { // SobolSamplerBuilder::new (sobol.rs:35-60) + table rows
     const uint32_t *matrices; // [1024*52]
     const uint32_t *bytetab;  // optional [SOBOL_TAB_DIMS][8][256]: XOR of the matrix columns selected by one index byte
+    const uint32_t *nibtab;   // optional [1024][SOBOL_NIBBLES][16]: the same per index nibble (what the shade kernels stage into LDS)
     const uint64_t *vdc;      // row m-1 of VD_C_SOBOL_MATRICES
     const uint64_t *vdc_inv;  // row m-1 of VD_C_SOBOL_MATRICES_INV
     uint32_t log2_res;
@@ -187,7 +193,11 @@ struct DPaths {
 
 // queue counters: one row of uint32 per loop iteration
 enum { Q_EXT = 0, Q_SHADOW = 1, Q_MIS = 2, Q_NEE = 3, Q_MAT0 = 4, Q_NUM_MAT = 7, Q_STRIDE = 16 };
-enum { CNT_EXT = 0, CNT_SHADOW = 1, CNT_MIS = 2, CNT_NODES = 3, CNT_TRIS = 4, CNT_NUM = 8 };
+enum { CNT_EXT = 0, CNT_SHADOW = 1, CNT_MIS = 2, CNT_NODES = 3, CNT_TRIS = 4,
+       CNT_NODE_STEPS = 5, CNT_NODE_VISITS = 6, CNT_TRI_STEPS = 7, // refill kernels with PTRS_FLAG_COUNTERS: wave-level node / triangle steps x 64 and per-lane node visits (lane occupancy of each phase)
+       CNT_ERR = 8,                                                // PTRS_ERRFLAG_* raised by device code
+       CNT_STAMP0 = 16,                                            // diagnostic builds (-DPTRS_STAMPS): 12 phase clocks of k_shade
+       CNT_NUM = 32 };
 
 struct DQueues {
     uint32_t *ext[2];          // ping-pong extension-ray queues
@@ -206,12 +216,17 @@ PT_HD f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
 // register copy of a DTriShade, filled by wide loads
 struct TriRegs {
     f3 p0, p1, p2, n0, n1, n2, s0, s1, s2;
+    f3 ng, ssn, dpdu, dpdv; // per-triangle constants (DTriShade v10-v12)
     f2 uv0, uv1, uv2;
     int32_t material, light, alpha_tex; uint32_t flags;
 };
-PT_HD TriRegs load_tri_regs(const DTriShade *rec) {
+PT_HD TriRegs load_tri_regs(const DTriShade *rec, bool want_dp = true) {
     const v4 *q = reinterpret_cast<const v4 *>(rec);
     TriRegs t;
+    const v4 k = q[10], l = q[11];
+    t.ng = mk3(k.x, k.y, k.z); t.ssn = mk3(k.w, l.x, l.y);
+    if (want_dp) { const v4 m = q[12]; t.dpdu = mk3(l.z, l.w, m.x); t.dpdv = mk3(m.y, m.z, m.w); }
+    else { t.dpdu = t.dpdv = mk3(0.0f, 0.0f, 0.0f); }
     const v4 a = q[0], b = q[1], c = q[2];
     t.p0 = mk3(a.x, a.y, a.z); t.p1 = mk3(a.w, b.x, b.y); t.p2 = mk3(b.z, b.w, c.x);
     t.material = (int32_t)f2u(c.y); t.light = (int32_t)f2u(c.z); t.flags = f2u(c.w);

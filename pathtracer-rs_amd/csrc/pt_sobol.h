@@ -54,6 +54,72 @@ PT_HD float sample_dimension(const DSampler &S, uint64_t index, uint32_t dim, ui
     return s;
 }
 
+// N dimensions >= 2 of one index at once: the same values as N sobol_sample calls, with all table reads issued before the
+// first one is needed (one memory round trip per shading vertex instead of one per dimension).
+template <int N>
+PT_HD void sobol_batch(const DSampler &S, uint64_t index, const uint32_t (&dim)[N], uint32_t scramble, float (&out)[N]) {
+    const uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+    uint32_t v[N];
+#ifdef PTRS_ABLATE_SOBOL // diagnostic builds only (tools/ablate.sh): no table reads, wrong values
+    for (int k = 0; k < N; ++k) { uint32_t w = (lo ^ scramble) * 2654435761u + dim[k] * 40503u; w ^= w >> 15; out[k] = min_(PT_ONE_MINUS_EPS, (float)(w * 2246822519u) * 0x1p-32f); }
+    return;
+#endif
+    bool tab = S.bytetab != nullptr;
+#pragma unroll
+    for (int k = 0; k < N; ++k) tab = tab && dim[k] < (uint32_t)SOBOL_TAB_DIMS;
+    if (tab) {
+        uint32_t a[N], b[N], c[N], d[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const uint32_t *t = S.bytetab + (size_t)dim[k] * (8u * 256u);
+            a[k] = t[lo & 255u]; b[k] = t[256u + ((lo >> 8) & 255u)]; c[k] = t[512u + ((lo >> 16) & 255u)]; d[k] = t[768u + (lo >> 24)];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = scramble ^ a[k] ^ b[k] ^ c[k] ^ d[k];
+        if (hi) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const uint32_t *t = S.bytetab + (size_t)dim[k] * (8u * 256u);
+                a[k] = t[1024u + (hi & 255u)]; b[k] = t[1280u + ((hi >> 8) & 255u)]; c[k] = t[1536u + ((hi >> 16) & 255u)]; d[k] = t[1792u + (hi >> 24)];
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] ^= a[k] ^ b[k] ^ c[k] ^ d[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            uint32_t w = scramble;
+            const uint32_t *mat = S.matrices + dim[k] * 52u;
+            for (uint64_t i = index; i != 0; i >>= 1, ++mat)
+                if (i & 1) w ^= *mat;
+            v[k] = w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = min_(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
+}
+
+// The dimensions one shading vertex draws, in the reference's order (integrator.rs:202-216, 453, 491): with next-event
+// estimation u_light (2-D), u_scatter (2-D), the light choice (1-D); then the BSDF sample (2-D) and the Russian-roulette
+// sample (1-D, drawn only inside its test).  get_2d's rule (dimension 4 is skipped, Q2) is applied to every 2-D draw.
+struct VertexDims { uint32_t nee[5], cont[2], rr; uint32_t after_nee, after_cont; };
+PT_HD VertexDims vertex_dims(uint32_t dim, bool nee) {
+    VertexDims V;
+    if (nee) {
+        if (dim == 4) dim = 5;
+        V.nee[0] = dim; V.nee[1] = dim + 1; dim += 2;
+        if (dim == 4) dim = 5;
+        V.nee[2] = dim; V.nee[3] = dim + 1; dim += 2;
+        V.nee[4] = dim; dim += 1;
+    } else { V.nee[0] = V.nee[1] = V.nee[2] = V.nee[3] = V.nee[4] = 2; }
+    V.after_nee = dim;
+    if (dim == 4) dim = 5;
+    V.cont[0] = dim; V.cont[1] = dim + 1; dim += 2;
+    V.after_cont = dim;
+    V.rr = dim;
+    return V;
+}
+
 // running sampler state of one path: index, dimension counter, pixel scramble
 struct SamplerState {
     uint64_t index;

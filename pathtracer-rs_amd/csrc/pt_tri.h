@@ -106,6 +106,8 @@ struct Surface {
     f2 uv;
     float dudx, dvdx, dudy, dvdy;
     int32_t prim;
+    f3 ssn;        // normalize(shading.dpdu) when it is known without computing it (ssn_ok): bsdf.rs:24 takes it as is
+    bool ssn_ok;
 };
 
 // shape.rs:217-356 + interaction.rs:128-175,193-214 (SurfaceMediumInteraction::new, set_shading_geometry)
@@ -113,7 +115,7 @@ PT_HD Surface tri_surface(const TriRegs &T, int32_t prim, float b0, float b1, fl
     Surface s;
     f3 p0 = T.p0, p1 = T.p1, p2 = T.p2;
     f2 uv0 = T.uv0, uv1 = T.uv1, uv2 = T.uv2;
-    tri_dpduv(p0, p1, p2, uv0, uv1, uv2, s.dpdu, s.dpdv);
+    s.dpdu = T.dpdu; s.dpdv = T.dpdv; // tri_dpduv(p0, p1, p2, uv0, uv1, uv2), evaluated on the host (DTriShade v10-v12)
     float xs = fabs_(b0 * p0.x) + fabs_(b1 * p1.x) + fabs_(b2 * p2.x);
     float ys = fabs_(b0 * p0.y) + fabs_(b1 * p1.y) + fabs_(b2 * p2.y);
     float zs = fabs_(b0 * p0.z) + fabs_(b1 * p1.z) + fabs_(b2 * p2.z);
@@ -123,11 +125,12 @@ PT_HD Surface tri_surface(const TriRegs &T, int32_t prim, float b0, float b1, fl
     s.wo = wo;
     s.prim = prim;
     s.dudx = s.dvdx = s.dudy = s.dvdy = 0.0f;
-    // geometric normal overrides normalize(dpdu x dpdv), shape.rs:260-266
-    s.n = normalize(cross(p0 - p2, p1 - p2));
-    if (((T.flags & TRI_REVERSE) != 0) != ((T.flags & TRI_SWAPS) != 0)) s.n = -s.n;
+    // geometric normal overrides normalize(dpdu x dpdv), shape.rs:260-266: normalize(cross(p0 - p2, p1 - p2)), flipped for
+    // reverse_orientation ^ transform_swaps_handedness -- a constant of the triangle (T.ng)
+    s.n = T.ng;
     s.ns = s.n;
     s.s_dpdu = s.dpdu; s.s_dpdv = s.dpdv;
+    s.ssn = T.ssn; s.ssn_ok = true; // normalize(dpdu)
     if (T.flags & (TRI_HAS_NORMAL | TRI_HAS_TANGENT)) {
         f3 ns;
         if (T.flags & TRI_HAS_NORMAL) {
@@ -137,8 +140,8 @@ PT_HD Surface tri_surface(const TriRegs &T, int32_t prim, float b0, float b1, fl
         f3 ss;
         if (T.flags & TRI_HAS_TANGENT) {
             ss = b0 * T.s0 + b1 * T.s1 + b2 * T.s2;
-            ss = len2(ss) > 0.0f ? normalize(ss) : normalize(s.dpdu);
-        } else ss = normalize(s.dpdu);
+            ss = len2(ss) > 0.0f ? normalize(ss) : T.ssn;
+        } else ss = T.ssn;
         f3 ts = cross(ss, ns);
         if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
         else coordinate_system(ns, ss, ts);
@@ -147,8 +150,17 @@ PT_HD Surface tri_surface(const TriRegs &T, int32_t prim, float b0, float b1, fl
         s.ns = normalize(cross(ss, ts));
         s.n = face_forward(s.n, s.ns);
         s.s_dpdu = ss; s.s_dpdv = ts;
+        s.ssn_ok = false;
     }
     return s;
+}
+
+// The per-triangle constants of DTriShade v10-v12, computed on the host when the scene is built.
+PT_HD void tri_constants(f3 p0, f3 p1, f3 p2, f2 uv0, f2 uv1, f2 uv2, uint32_t flags, f3 &ng, f3 &ssn, f3 &dpdu, f3 &dpdv) {
+    tri_dpduv(p0, p1, p2, uv0, uv1, uv2, dpdu, dpdv);
+    ng = normalize(cross(p0 - p2, p1 - p2));
+    if (((flags & TRI_REVERSE) != 0) != ((flags & TRI_SWAPS) != 0)) ng = -ng;
+    ssn = normalize(dpdu);
 }
 
 // compute_differentials, interaction.rs:216-281 (only camera rays carry differentials, Q9)

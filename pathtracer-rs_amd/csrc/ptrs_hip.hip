@@ -39,7 +39,9 @@ struct Options {
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
     int grid_mult = 1;        // workgroups per pass in units of the resident capacity (8 per CU)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
-    int vote = 1;             // traversal kernels: each step runs the phase (node visit / triangle test) most lanes of the wave are in
+    int vote = -1;            // lane-refill traversal kernels: each step runs the phase (node visit / triangle test) most lanes of the wave are in.
+                              // -1 = by scene: on for quad-form scenes (colonnade extend 86 -> 56 ms), off for LDS-resident pair form, whose cheap steps do not pay for the vote (Cornell 88 -> 92 ms)
+    int shade_lds = 1;        // shade kernels read light records, small scenes' triangle records and the round's Sobol' tables from LDS (0: everything from global memory)
     int workspace_pct = 40;   // the render workspace (path state + queues of all lanes) may take this share of the device memory that is free at the call
 };
 Options g_opt;
@@ -48,7 +50,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, 0, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
+    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 1}, {"shade_lds", &Options::shade_lds, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -242,27 +244,32 @@ __device__ inline uint32_t rf_take(uint32_t *cursor, unsigned long long idle) {
 // does: every descending lane reaches a leaf), so at least half of the lanes holding rays work in every step.  Each ray still
 // makes exactly the visits and tests of the while-while loop in the same order: results are identical.
 // (Measured, single lane, VALU lanes active per instruction / ms per frame: see DESIGN.md section 4.)
-template <bool QUAD, bool ALPHA, class Stack, class Geom>
-__device__ inline void rf_step(const Geom &G, const DScene &sc, bool vote, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
-                               Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt) {
-    if (vote) {
+struct StepCount { uint32_t node_steps = 0, node_visits = 0, tri_steps = 0; }; // counters_on only: steps count 64 per wave-level step (added by the wave's first active lane)
+__device__ inline uint32_t first_lane_64() { return (int)__lane_id() == __ffsll((long long)__ballot(true)) - 1 ? 64u : 0u; }
+template <bool VOTE, bool QUAD, bool ALPHA, class Stack, class Geom>
+__device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
+                               Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt, bool count, StepCount &sc_n) {
+    if (VOTE) {
         const bool at_node = r_cur != REF_NONE && !(r_cur & REF_LEAF), at_leaf = r_cur != REF_NONE && (r_cur & REF_LEAF); // lanes without a ray hold REF_NONE
         if (__popcll(__ballot(at_node)) >= __popcll(__ballot(at_leaf))) {
-            if (at_node) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
+            if (at_node) { if (count) { sc_n.node_steps += first_lane_64(); ++sc_n.node_visits; } node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
         } else if (at_leaf) {
+            if (count) sc_n.tri_steps += first_lane_64();
             const bool done = leaf_step<ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt);
             if (done) r_cur = REF_NONE; else if (r_cur == REF_NONE) r_cur = pop_next_ref<false>(stk, r_tmax);
         }
         return;
     }
-    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn);
-    if (r_cur != REF_NONE) { const bool done = leaf_test<false, ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax); }
+    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { if (count) { sc_n.node_steps += first_lane_64(); ++sc_n.node_visits; } node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
+    if (r_cur != REF_NONE) {
+        if (count) { const uint32_t k = ((r_cur >> REF_COUNT_SHIFT) & 15u) + 1u; uint32_t kmax = k; for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kmax, off); kmax = o > kmax ? o : kmax; } sc_n.tri_steps += first_lane_64() * kmax; } // (lanes outside this branch contribute their stale k: an upper bound, diagnostic only)
+        const bool done = leaf_test<false, ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax);
+    }
 }
 
-template <int FEAT, int DEPTH, bool OVF, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh_vote) {
+template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
+__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8; // quad form with the small stack column: the tree's top lives in LDS
-    const uint32_t thresh = thresh_vote & 0xffu; const bool vote = (thresh_vote & 0x100u) != 0;
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
     __shared__ uint32_t cursor;
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
     const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_EXT, Gn, b);
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-    uint32_t nn = 0, nt = 0, pid = 0;
+    uint32_t nn = 0, nt = 0, pid = 0; StepCount stepc;
     bool has = false, dry = n == 0; // has: the lane holds an unfinished ray; dry: the segment has no rays left for this wave
     RF_DECL
     for (;;) {
@@ -299,20 +306,19 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
         }
         if (!__any(has)) break; // every ray of the segment this wave could get is retired
         do { // steps until a lane finishes its ray: only then is there something to retire or refill
-            if (GEOM > 0) rf_step<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false);
-            else rf_step<true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false);
-        } while (vote && !__any(has && r_cur == REF_NONE));
+            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, R.counters_on != 0, stepc);
+            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, R.counters_on != 0, stepc);
+        } while (VOTE && !__any(has && r_cur == REF_NONE));
     }
-    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
+    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
 // The two scene queries of a pending NEE record with lane refill: a lane walks the shadow ray (any hit), then the MIS
 // ray (closest hit) of its record and leaves the answers in the path state (NEE_OCCLUDED in nee2.w, the MIS hit in
 // `hit`, which the shade stage has consumed by now); k_resolve turns them into radiance with full waves.
-template <int FEAT, int DEPTH, bool OVF, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh_vote) {
+template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
+__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8;
-    const uint32_t thresh = thresh_vote & 0xffu; const bool vote = (thresh_vote & 0x100u) != 0;
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
     __shared__ uint32_t cursor;
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
     const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_NEE, Gn, b);
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-    uint32_t nn = 0, nt = 0, pid = 0, fl = 0;
+    uint32_t nn = 0, nt = 0, pid = 0, fl = 0; StepCount stepc;
     bool has = false, dry = n == 0, shadow_phase = false, setup = false;
     RF_DECL
     for (;;) {
@@ -358,11 +364,11 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
         }
         if (!__any(has)) break;
         do {
-            if (GEOM > 0) rf_step<false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase);
-            else rf_step<true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, vote, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase);
-        } while (vote && !__any(has && r_cur == REF_NONE));
+            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, R.counters_on != 0, stepc);
+            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, R.counters_on != 0, stepc);
+        } while (VOTE && !__any(has && r_cur == REF_NONE));
     }
-    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
+    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
 // estimate_direct's use of the two answers (integrator.rs:66-78, 121-134) and `l += beta * nLights * ld`, full waves
@@ -415,12 +421,89 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
 // Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X: the Matte / FEAT_SIMPLE kernel (175
 // VGPRs unconstrained -> 2 waves) gains 9 % at 3 waves (168 VGPRs, no scratch growth); the FEAT_FULL kernels (up to 256
 // VGPRs) lose 5 % to spills when pressed to 3 and every kernel loses at 4.
-template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT == FEAT_SIMPLE) ? 3 : 1 }; };
+#ifndef PTRS_SHADE_WAVES_MATTE
+#define PTRS_SHADE_WAVES_MATTE 2
+#endif
+template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT == FEAT_SIMPLE) ? PTRS_SHADE_WAVES_MATTE : 2 }; }; // 2: never above 256 registers (one wave per SIMD otherwise)
+
+// The shade kernels' read-only tables in LDS.  A shading vertex issues ~150 vector-memory instructions -- path state,
+// the triangle's record, 32 Sobol' table words, the light's record, spills -- and the kernel's time is the time the
+// CU's address unit needs for them (TA busy 70 %, 37 busy cycles per instruction; VALU half idle; HBM at a fifth of its
+// rate).  What is small and shared by all paths therefore moves into LDS once per workgroup:
+//   * the light records (<= SH_LIGHTS of them),
+//   * the triangles' shading records when the scene has <= SH_TRI_V4 / 13 triangles (Cornell: 36),
+//   * the Sobol' tables of the dimensions this round can draw, in nibble form (16 words per index nibble and dimension):
+//     a sample is scramble ^ XOR of 8 (32-bit index) or 13 LDS words instead of 4 or 8 words gathered from L2.
+enum : uint32_t { SH_SOB_WORDS = 6144, SH_TRI_V4 = 1024, SH_LIGHTS = 16, SH_LIGHT_V4 = sizeof(DLight) / 16, SH_TRI_REC_V4 = sizeof(DTriShade) / 16 };
+static_assert(sizeof(DLight) % 16 == 0 && sizeof(DTriShade) % 16 == 0, "records are staged as 16-byte vectors");
+struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds; }; // Sobol' window [sob_lo, sob_lo + sob_n), nibbles staged per dimension
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+PT_HD uint32_t sob_stride(uint32_t nib) { return nib * 16u + 4u; } // words per dimension; + 4: consecutive dimensions start 4 banks apart
+struct ShadeCtxLds {
+    lds_u32 *sob; lds_v4 *tris, *lights; ShadeLdsCfg cfg;
+    __device__ inline v4 ld(lds_v4 *q) const { v4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
+    __device__ inline TriRegs tri(const DScene &sc, int32_t prim, bool want_dp) const {
+        if (!cfg.tri_lds) return load_tri_regs(sc.shade + prim, want_dp);
+        v4 r[SH_TRI_REC_V4];
+        lds_v4 *q = tris + (uint32_t)prim * SH_TRI_REC_V4;
+#pragma unroll
+        for (uint32_t k = 0; k < SH_TRI_REC_V4; ++k) r[k] = ld(q + k);
+        return load_tri_regs(reinterpret_cast<const DTriShade *>(r), want_dp);
+    }
+    __device__ inline void before_stores() const { __builtin_amdgcn_s_waitcnt(0x0F70); } // vmcnt(0): the next item's state has landed in LDS (k_shade)
+    __device__ inline void light(const DScene &sc, uint32_t li, DLight &out) const {
+        if (li >= cfg.n_lights_lds) { out = sc.lights[li]; return; }
+        v4 *o = reinterpret_cast<v4 *>(&out);
+        lds_v4 *q = lights + li * SH_LIGHT_V4;
+#pragma unroll
+        for (uint32_t k = 0; k < SH_LIGHT_V4; ++k) o[k] = ld(q + k);
+    }
+    template <int N> __device__ inline void sobol(const DSampler &S, uint64_t index, const uint32_t (&dim)[N], uint32_t scramble, float (&out)[N]) const {
+        const uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+        bool in = cfg.sob_nib >= 13u || (hi == 0u && cfg.sob_nib >= 8u); // every set bit of the index has its nibble staged
+#pragma unroll
+        for (int k = 0; k < N; ++k) in = in && dim[k] - cfg.sob_lo < cfg.sob_n;
+        if (!in) { sobol_batch<N>(S, index, dim, scramble, out); return; } // outside this round's window: the global tables
+        const uint32_t stride = sob_stride(cfg.sob_nib);
+        uint32_t v[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            lds_u32 *t = sob + (dim[k] - cfg.sob_lo) * stride;
+            v[k] = scramble ^ t[lo & 15u] ^ t[16u + ((lo >> 4) & 15u)] ^ t[32u + ((lo >> 8) & 15u)] ^ t[48u + ((lo >> 12) & 15u)] ^ t[64u + ((lo >> 16) & 15u)] ^ t[80u + ((lo >> 20) & 15u)] ^
+                   t[96u + ((lo >> 24) & 15u)] ^ t[112u + (lo >> 28)];
+        }
+        if (cfg.sob_nib > 8u) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                lds_u32 *t = sob + (dim[k] - cfg.sob_lo) * stride;
+                v[k] ^= t[128u + (hi & 15u)] ^ t[144u + ((hi >> 4) & 15u)] ^ t[160u + ((hi >> 8) & 15u)] ^ t[176u + ((hi >> 12) & 15u)] ^ t[192u + ((hi >> 16) & 15u)];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = min_(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
+    }
+};
+
 template <int MAT, int FEAT>
-__global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
+__global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, ShadeLdsCfg cfg) {
     __shared__ uint32_t lcount[4]; // next, nee, shadow rays, mis rays
+    __shared__ uint32_t finished;   // waves of this workgroup that are through their items
+    __shared__ v4 lds_pf[5 * BLOCK]; // the next item's path state per thread, filled by LDS-DMA
+    __shared__ uint32_t lds_sob[SH_SOB_WORDS];
+    __shared__ v4 lds_tri[SH_TRI_V4];
+    __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
+    bool err_dim = false;
     if (threadIdx.x < 4) lcount[threadIdx.x] = 0;
+    if (threadIdx.x == 4) finished = 0;
+    {
+        const uint32_t stride = sob_stride(cfg.sob_nib), nw = cfg.sob_nib * 16u;
+        for (uint32_t i = threadIdx.x; i < cfg.sob_n * stride; i += BLOCK) { const uint32_t d = i / stride, w = i - d * stride; lds_sob[i] = w < nw ? S.nibtab[((size_t)(cfg.sob_lo + d) * SOBOL_NIBBLES) * 16u + w] : 0u; }
+        if (cfg.tri_lds) { const v4 *g = reinterpret_cast<const v4 *>(sc.shade); for (uint32_t i = threadIdx.x; i < sc.n_prims * SH_TRI_REC_V4; i += BLOCK) lds_tri[i] = g[i]; }
+        const v4 *gl = reinterpret_cast<const v4 *>(sc.lights);
+        for (uint32_t i = threadIdx.x; i < cfg.n_lights_lds * SH_LIGHT_V4; i += BLOCK) lds_light[i] = gl[i];
+    }
     __syncthreads();
+    ShadeCtxLds X; X.sob = (lds_u32 *)lds_sob; X.tris = (lds_v4 *)lds_tri; X.lights = (lds_v4 *)lds_light; X.cfg = cfg;
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_MAT0 + MAT, G, b);
@@ -428,22 +511,69 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
     const uint32_t next_base = *seg_count(Q, it + 1u, Q_EXT, G, b), nee_base = *seg_count(Q, it, Q_NEE, G, b);
     uint32_t *next = Q.ext[(it + 1u) & 1u] + (size_t)b * seg_cap + next_base;
     uint32_t *nee = Q.nee + (size_t)b * seg_cap + nee_base;
-    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
-        const uint32_t pid = queue[i];
-        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid);
+#ifdef PTRS_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+    // Software pipeline through LDS.  A vertex needs 80 bytes of its path out of HBM before it can start, and nothing else
+    // of this stage waits for HBM: the wave asks for the NEXT item's five vectors with LDS-DMA loads (global_load_lds_dwordx4:
+    // no registers held while they fly) before it shades the current item, and shade_item waits for them right before it issues
+    // its stores (before_stores) -- by then they have had a whole vertex's time to arrive.  The queue entry is read two items
+    // ahead.  Vector k of wave w sits at lds_pf[(k * 4 + w) * 64 + lane].
+    const uint32_t wv = threadIdx.x >> 6;
+    auto dma = [&](uint32_t p) {
+        typedef __attribute__((address_space(1))) const void gptr; typedef __attribute__((address_space(3))) void lptr;
+        __builtin_amdgcn_global_load_lds((gptr *)(P.ray_o + p), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)(P.ray_d + p), (lptr *)(lds_pf + (1u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)(P.beta + p), (lptr *)(lds_pf + (2u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)(P.st + p), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)(P.hit + p), (lptr *)(lds_pf + (4u * 4u + wv) * 64u), 16, 0, 0);
+    };
+    uint32_t i = threadIdx.x, pid = 0, pid1 = 0;
+    if (i < n) { pid = queue[i]; dma(pid); }
+    if (i + BLOCK < n) pid1 = queue[i + BLOCK];
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first item's state is in LDS
+    while (i < n) {
+        PathIn in;
+        {
+            lds_v4 *q = (lds_v4 *)lds_pf + threadIdx.x;
+            in.ro = X.ld(q); in.rd = X.ld(q + BLOCK); in.beta = X.ld(q + 2 * BLOCK);
+            const v4 a = X.ld(q + 3 * BLOCK), c = X.ld(q + 4 * BLOCK);
+            in.st.x = f2u(a.x); in.st.y = f2u(a.y); in.st.z = f2u(a.z); in.st.w = f2u(a.w);
+            in.hit.x = f2u(c.x); in.hit.y = f2u(c.y); in.hit.z = f2u(c.z); in.hit.w = f2u(c.w);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS reads are done before the next DMA overwrites the buffer
+        const uint32_t i2 = i + BLOCK;
+        if (i2 < n) dma(pid1);
+        uint32_t pid2 = 0;
+        if (i2 + BLOCK < n) pid2 = queue[i2 + BLOCK];
+#ifdef PTRS_STAMPS
+        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X, stamp_acc, stamp_last);
+        { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[9] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; } // early returns land here
+#else
+        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X);
+#endif
+        err_dim = err_dim || r.err_dim;
         uint32_t slot = block_push(&lcount[0], r.next);
         if (r.next) next[slot] = pid;
         slot = block_push(&lcount[1], r.nee);
         if (r.nee) nee[slot] = pid;
         block_count(&lcount[2], r.shadow);
         block_count(&lcount[3], r.mis);
+        i = i2; pid = pid1; pid1 = pid2;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *seg_count(Q, it + 1u, Q_EXT, G, b) = next_base + lcount[0];
-        *seg_count(Q, it, Q_NEE, G, b) = nee_base + lcount[1];
-        *seg_count(Q, it, Q_SHADOW, G, b) += lcount[2];
-        *seg_count(Q, it, Q_MIS, G, b) += lcount[3];
+    // No barrier at the end: a wave that has finished leaves (its registers go to the next workgroup's waves); the last
+    // of the four publishes the segment's counts.  A wave's LDS atomics execute in order, so when the last wave's
+    // increment of `finished` returns 3, every push of the other three has been counted.
+    if (err_dim) atomicOr(&Q.stats[CNT_ERR], (unsigned long long)PTRS_ERRFLAG_SOBOL_DIM);
+#ifdef PTRS_STAMPS
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[11] += t_ - stamp_last; }
+    if ((threadIdx.x & 63u) == 0) for (int k = 0; k < 12; ++k) atomicAdd(&Q.stats[CNT_STAMP0 + k], stamp_acc[k]);
+#endif
+    if ((threadIdx.x & 63u) == 0 && atomicAdd(&finished, 1u) == BLOCK / 64 - 1) {
+        *seg_count(Q, it + 1u, Q_EXT, G, b) = next_base + atomicAdd(&lcount[0], 0u);
+        *seg_count(Q, it, Q_NEE, G, b) = nee_base + atomicAdd(&lcount[1], 0u);
+        *seg_count(Q, it, Q_SHADOW, G, b) += atomicAdd(&lcount[2], 0u);
+        *seg_count(Q, it, Q_MIS, G, b) += atomicAdd(&lcount[3], 0u);
     }
 }
 
@@ -563,7 +693,7 @@ template <class T> int upload(DevBuf &b, const std::vector<T> &v) {
 
 struct SobolDevice { // one copy per device
     int device = -1;
-    DevBuf matrices, vdc, vdc_inv, bytetab;
+    DevBuf matrices, vdc, vdc_inv, bytetab, nibtab;
     uint32_t stride = 52;
 };
 std::mutex g_mu;
@@ -579,7 +709,9 @@ int get_sobol(int device, SobolDevice **out) {
     const unsigned char *pm = b + 32, *pv = pm + nmat * 4 + 52 * 4, *pvi = pv + (size_t)hdr[2] * stride * 8;
     auto *s = new SobolDevice(); s->device = device; s->stride = (uint32_t)stride;
     int rc;
-    if ((rc = s->matrices.ensure(nmat * 4)) != PTRS_OK || (rc = s->vdc.ensure((size_t)hdr[2] * stride * 8)) != PTRS_OK || (rc = s->vdc_inv.ensure((size_t)hdr[3] * stride * 8)) != PTRS_OK) { delete s; return rc; }
+    const size_t mat_pad = 16 * 52 * 4; // a path that overruns the 1024 dimensions reads up to 8 rows past the table before its kernel raises PTRS_ERRFLAG_SOBOL_DIM
+    if ((rc = s->matrices.ensure(nmat * 4 + mat_pad)) != PTRS_OK || (rc = s->vdc.ensure((size_t)hdr[2] * stride * 8)) != PTRS_OK || (rc = s->vdc_inv.ensure((size_t)hdr[3] * stride * 8)) != PTRS_OK) { delete s; return rc; }
+    HIPCHK(hipMemset(s->matrices.p, 0, nmat * 4 + mat_pad));
     HIPCHK(hipMemcpy(s->matrices.p, pm, nmat * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->vdc.p, pv, (size_t)hdr[2] * stride * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->vdc_inv.p, pvi, (size_t)hdr[3] * stride * 8, hipMemcpyHostToDevice));
@@ -588,6 +720,18 @@ int get_sobol(int device, SobolDevice **out) {
         std::vector<uint32_t> bt; build_sobol_bytetab(T, bt);
         if ((rc = s->bytetab.ensure(bt.size() * 4)) != PTRS_OK) { delete s; return rc; }
         HIPCHK(hipMemcpy(s->bytetab.p, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
+        // nibtab[dim][n][v] = XOR of the matrix columns 4n + j over the set bits j of v: the form the shade kernels stage into
+        // LDS (64 B per index nibble and dimension; the byte tables above would need 1 KB)
+        std::vector<uint32_t> nt((size_t)1024 * SOBOL_NIBBLES * 16, 0u);
+        for (uint32_t d = 0; d < 1024; ++d)
+            for (uint32_t n = 0; n < (uint32_t)SOBOL_NIBBLES; ++n)
+                for (uint32_t v = 0; v < 16; ++v) {
+                    uint32_t x = 0;
+                    for (uint32_t j = 0; j < 4; ++j) if ((v >> j) & 1u) { const uint32_t col = 4 * n + j; if (col < 52) x ^= T.matrices[(size_t)d * 52 + col]; }
+                    nt[((size_t)d * SOBOL_NIBBLES + n) * 16 + v] = x;
+                }
+        if ((rc = s->nibtab.ensure(nt.size() * 4)) != PTRS_OK) { delete s; return rc; }
+        HIPCHK(hipMemcpy(s->nibtab.p, nt.data(), nt.size() * 4, hipMemcpyHostToDevice));
     }
     g_sobol.push_back(s);
     *out = s;
@@ -661,6 +805,7 @@ struct HipBackend {
     }
     int grid_max = 2048;
     uint32_t refill_connect = 16;
+    bool vote = true;
     uint32_t refill = 16; // idle-lane threshold of the lane-refill kernels; 0 = the fused k_extend / k_connect (PTRS_REFILL)
     int rc = PTRS_OK;
     // timing
@@ -670,6 +815,7 @@ struct HipBackend {
 
     const uint32_t *sobol_matrices() { return (const uint32_t *)sob->matrices.p; }
     const uint32_t *sobol_bytetab() { return (const uint32_t *)sob->bytetab.p; }
+    const uint32_t *sobol_nibtab() { return (const uint32_t *)sob->nibtab.p; }
     const uint64_t *sobol_vdc(uint32_t row) { return (const uint64_t *)sob->vdc.p + (size_t)row * sob->stride; }
     const uint64_t *sobol_vdc_inv(uint32_t row) { return (const uint64_t *)sob->vdc_inv.p + (size_t)row * sob->stride; }
 
@@ -690,6 +836,7 @@ struct HipBackend {
         // colonnade (quad form) none 1517, extend 1698, both 1830
         refill_connect = opt.refill_connect >= 0 ? (uint32_t)opt.refill_connect : (sc.n_nodes4 ? 16u : 0u);
         refill = (uint32_t)opt.refill;
+        vote = opt.vote >= 0 ? opt.vote != 0 : sc.n_nodes4 != 0;
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
@@ -739,7 +886,7 @@ struct HipBackend {
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill) {
-#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill | (opt.vote ? 0x100u : 0u))
+#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); } while (0)
             if (ps->stack_lds == 8) {
                 if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
                 else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
@@ -765,7 +912,7 @@ struct HipBackend {
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill_connect) {
-#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect | (opt.vote ? 0x100u : 0u))
+#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect); else hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect); } while (0)
             if (ps->stack_lds == 8) {
                 if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
                 else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
@@ -785,15 +932,29 @@ struct HipBackend {
 #undef PTRS_LAUNCH
     }
     void connect(uint32_t it) { t0(T_CONNECT); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
+    // The Sobol' dimensions a vertex of round `it` can draw: a path starts the round at dimension <= 3 + 8 it (two camera
+    // dimensions, the skipped dimension 4, at most 8 per vertex before) and draws at most 9 further ones; the window staged
+    // into LDS is the top of that range (paths below it -- long specular chains -- read the global tables).
+    ShadeLdsCfg shade_cfg(uint32_t it) const {
+        ShadeLdsCfg c;
+        c.sob_nib = (2u * S.log2_res + (31u - (uint32_t)__builtin_clz(S.spp)) <= 32u) ? 8u : (uint32_t)SOBOL_NIBBLES;
+        const uint32_t cap = SH_SOB_WORDS / sob_stride(c.sob_nib), top = std::min<uint32_t>(1024u, 3u + 8u * it + 9u);
+        c.sob_lo = top > cap ? top - cap : 0u; c.sob_n = top - c.sob_lo;
+        c.tri_lds = (sc.n_prims * SH_TRI_REC_V4 <= SH_TRI_V4 && opt.shade_lds) ? 1u : 0u;
+        c.n_lights_lds = opt.shade_lds ? std::min<uint32_t>(sc.n_lights, SH_LIGHTS) : 0u;
+        if (!opt.shade_lds) c.sob_n = 0;
+        return c;
+    }
     template <int FEAT> void shade_t(uint32_t it, int kind) {
         dim3 g(G), b(BLOCK);
+        const ShadeLdsCfg cfg = shade_cfg(it);
         switch (kind) {
-            case 0: hipLaunchKernelGGL((k_shade<0, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
-            case 1: hipLaunchKernelGGL((k_shade<1, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
-            case 2: hipLaunchKernelGGL((k_shade<2, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
-            case 3: hipLaunchKernelGGL((k_shade<3, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
-            case 4: hipLaunchKernelGGL((k_shade<4, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
-            default: hipLaunchKernelGGL((k_shade<5, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap); break;
+            case 0: hipLaunchKernelGGL((k_shade<0, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
+            case 1: hipLaunchKernelGGL((k_shade<1, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
+            case 2: hipLaunchKernelGGL((k_shade<2, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
+            case 3: hipLaunchKernelGGL((k_shade<3, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
+            case 4: hipLaunchKernelGGL((k_shade<4, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
+            default: hipLaunchKernelGGL((k_shade<5, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
         }
     }
     void shade(uint32_t it, int kind) {
@@ -829,7 +990,8 @@ struct HipBackend {
         if (le != hipSuccess) { g_err = std::string("kernel launch failed: ") + hipGetErrorString(le); rc = PTRS_ERR_DEVICE; }
         unsigned long long hs[CNT_NUM] = {0};
         (void)hipMemcpy(hs, Q.stats, sizeof(hs), hipMemcpyDeviceToHost);
-        st.nodes_visited = hs[CNT_NODES]; st.tris_tested = hs[CNT_TRIS];
+        st.nodes_visited = hs[CNT_NODES]; st.tris_tested = hs[CNT_TRIS]; st.node_steps_x64 = hs[CNT_NODE_STEPS]; st.node_visits = hs[CNT_NODE_VISITS]; st.tri_steps_x64 = hs[CNT_TRI_STEPS]; st.error_flags = hs[CNT_ERR];
+        for (int k = 0; k < 12; ++k) st.debug[k] = hs[CNT_STAMP0 + k];
         st.kernel_launches = launches; st.trace_launches = trace_launches;
         for (auto &s : spans) {
             float ms = 0.0f;
@@ -1071,7 +1233,7 @@ int ptrs_sobol_samples(const PtrsRenderParams *params, uint32_t n, const int32_t
     int rc = get_sobol(params->device, &sob);
     if (rc != PTRS_OK) return rc;
     DSampler S;
-    S.matrices = (const uint32_t *)sob->matrices.p; S.bytetab = (const uint32_t *)sob->bytetab.p; S.vdc = (const uint64_t *)sob->vdc.p + (size_t)(g.log2_res - 1) * sob->stride; S.vdc_inv = (const uint64_t *)sob->vdc_inv.p + (size_t)(g.log2_res - 1) * sob->stride;
+    S.matrices = (const uint32_t *)sob->matrices.p; S.bytetab = (const uint32_t *)sob->bytetab.p; S.nibtab = (const uint32_t *)sob->nibtab.p; S.vdc = (const uint64_t *)sob->vdc.p + (size_t)(g.log2_res - 1) * sob->stride; S.vdc_inv = (const uint64_t *)sob->vdc_inv.p + (size_t)(g.log2_res - 1) * sob->stride;
     S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
     DevBuf bx, by, bn, bdm, bo, bi;
     auto cleanup = [&]() { bx.release(); by.release(); bn.release(); bdm.release(); bo.release(); bi.release(); };

@@ -37,7 +37,7 @@ struct CheckedStack {
 };
 
 struct HostBackend {
-    bool overflow = false; int stack_cap = 128;
+    bool overflow = false, err_dim = false; int stack_cap = 128;
     CheckedStack make_stack() { CheckedStack k; k.cap = stack_cap; k.overflow = &overflow; return k; }
     DScene sc; DSampler S; DCamera C; DParams R; DPaths P; DQueues Q;
     std::vector<std::vector<unsigned char>> pool;
@@ -48,6 +48,7 @@ struct HostBackend {
 
     const uint32_t *sobol_matrices() { return g_tables.matrices.data(); }
     const uint32_t *sobol_bytetab() { return g_use_bytetab ? g_bytetab.data() : nullptr; }
+    const uint32_t *sobol_nibtab() { return nullptr; }
     const uint64_t *sobol_vdc(uint32_t row) { return g_tables.vdc.data() + (size_t)row * g_tables.stride; }
     const uint64_t *sobol_vdc_inv(uint32_t row) { return g_tables.vdc_inv.data() + (size_t)row * g_tables.stride; }
 
@@ -97,6 +98,7 @@ struct HostBackend {
             const uint32_t pid = q[i];
             const ShadeResult r = feat == FEAT_SIMPLE ? shade_dispatch<FEAT_SIMPLE>(kind, R, S, C, sc, P, pid) : feat == FEAT_IMG ? shade_dispatch<FEAT_IMG>(kind, R, S, C, sc, P, pid)
                                 : feat == FEAT_IMG_ENV ? shade_dispatch<FEAT_IMG_ENV>(kind, R, S, C, sc, P, pid) : shade_dispatch<FEAT_FULL>(kind, R, S, C, sc, P, pid);
+            err_dim = err_dim || r.err_dim;
             if (r.next) next[cnt(it + 1, Q_EXT)++] = pid;
             if (r.shadow) cnt(it, Q_SHADOW)++;
             if (r.mis) cnt(it, Q_MIS)++;
@@ -124,7 +126,7 @@ struct HostBackend {
             out[o] = P.L[pid].x; out[o + 1] = P.L[pid].y; out[o + 2] = P.L[pid].z;
         }
     }
-    void end(PtrsStats &st) { st.nodes_visited = nodes; st.tris_tested = tris; if (overflow) st.kernel_launches = 0xdeadull; }
+    void end(PtrsStats &st) { st.nodes_visited = nodes; st.tris_tested = tris; if (overflow) st.kernel_launches = 0xdeadull; if (err_dim) st.error_flags |= PTRS_ERRFLAG_SOBOL_DIM; }
 };
 
 } // namespace
@@ -134,6 +136,7 @@ extern "C" {
 const char *twin_last_error(void) { return g_err.c_str(); }
 int twin_load_tables(const char *path) {
     if (!load_sobol_tables(path, g_tables)) return PTRS_ERR_IO;
+    g_tables.matrices.resize(g_tables.matrices.size() + 16 * 52, 0u); // head-room for a path that overruns the 1024 dimensions (it raises PTRS_ERRFLAG_SOBOL_DIM)
     build_sobol_bytetab(g_tables, g_bytetab);
     return PTRS_OK;
 }
@@ -183,7 +186,7 @@ int twin_sobol_samples(const PtrsRenderParams *prm, uint32_t n, const int32_t *p
     if (!g_tables.ok) { g_err = "tables not loaded"; return PTRS_ERR_INVALID; }
     SampleGrid g = make_sample_grid(prm->width, prm->height, prm->spp);
     DSampler S;
-    S.matrices = g_tables.matrices.data(); S.bytetab = g_use_bytetab ? g_bytetab.data() : nullptr; S.vdc = g_tables.vdc.data() + (size_t)(g.log2_res - 1) * g_tables.stride; S.vdc_inv = g_tables.vdc_inv.data() + (size_t)(g.log2_res - 1) * g_tables.stride;
+    S.matrices = g_tables.matrices.data(); S.bytetab = g_use_bytetab ? g_bytetab.data() : nullptr; S.nibtab = nullptr; S.vdc = g_tables.vdc.data() + (size_t)(g.log2_res - 1) * g_tables.stride; S.vdc_inv = g_tables.vdc_inv.data() + (size_t)(g.log2_res - 1) * g_tables.stride;
     S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
     for (uint32_t i = 0; i < n; ++i) {
         uint64_t idx = sobol_index(S, sample_nums[i], (uint32_t)(px[i] - g.min_x), (uint32_t)(py[i] - g.min_y));

@@ -60,6 +60,19 @@ def test_detmath_is_correctly_rounded_on_samples(orc):
     assert L.orc_detmath(6, 0.0, -1.0) == float(np.float32(math.pi))
 
 
+def test_fused_sincos_equals_sin_and_cos(orc):
+    """pt_sincosf (one reduction, both polynomials once; what the device's cosine-hemisphere and environment sampling call)
+    returns bit for bit what pt_sinf and pt_cosf return -- the oracle keeps calling those two."""
+    L = orc.lib()
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-8, 8, 40000), rng.uniform(-1e4, 1e4, 5000), [0.0, -0.0, np.pi / 4, np.pi / 2, np.pi, 3 * np.pi / 2, 1e-30, np.inf, np.nan]]).astype(np.float32)
+    for x in xs:
+        s0, c0 = np.float32(L.orc_detmath(0, float(x), 0.0)), np.float32(L.orc_detmath(1, float(x), 0.0))
+        s1, c1 = np.float32(L.orc_detmath(9, float(x), 0.0)), np.float32(L.orc_detmath(10, float(x), 0.0))
+        assert s0.view(np.uint32) == s1.view(np.uint32) or (np.isnan(s0) and np.isnan(s1)), x
+        assert c0.view(np.uint32) == c1.view(np.uint32) or (np.isnan(c0) and np.isnan(c1)), x
+
+
 def _tables():
     raw = open(os.path.join(ROOT, "data", "sobol_tables.bin"), "rb").read()
     assert raw[:8] == b"PTRSSOB1"

@@ -18,7 +18,7 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   echo "pmc pass $i: $SET"
-  rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- $CMD > "$OUT/pmc$i.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- $CMD > "$OUT/pmc$i.log" 2>&1
 done
 python3 tools/summarize_pmc.py "$OUT/pmc.csv" "$OUT"/pmc[0-9]
 python3 tools/prof_report.py "$OUT" --json "$OUT/pmc.json" --frames $FR --workload $W --commit "${COMMIT:-?}" > "$OUT/report.txt"
