@@ -41,6 +41,7 @@ PT_HD CamRay camera_ray(const DCamera &C, f2 pf, float diff_scale) {
 
 struct PathCoord { int32_t sx, sy, px, py; uint32_t s; };
 PT_HD PathCoord path_coord(const DParams &R, const DSampler &S, uint32_t pid) {
+    if (R.pixel_mode) { PathCoord c; c.s = R.s0 + pid; c.sx = R.pix_sx; c.sy = R.pix_sy; c.px = S.min_x + c.sx; c.py = S.min_y + c.sy; return c; }
     const uint32_t npix = (uint32_t)(R.row1 - R.row0) * (uint32_t)R.NX;
     uint32_t pl = pid % npix;
     PathCoord c;

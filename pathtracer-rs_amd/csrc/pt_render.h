@@ -111,7 +111,9 @@ inline int scene_trace_features(const HostScene &H) {
 
 template <class BE>
 int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_t bvh_depth, const PtrsCamera &cam, const PtrsRenderParams &prm,
-                v4 *film /* backend memory, W*H */, float *samples_out /* backend memory or null */, PtrsStats *stats, std::string &err) {
+                v4 *film /* backend memory, W*H */, float *samples_out /* backend memory or null */, PtrsStats *stats, std::string &err,
+                const int32_t *single_pixel = nullptr /* render_single_pixel (integrator.rs:505-534): raster (px, py), any pixel of the sample bounds;
+                                                         traces that pixel's spp paths only, no film, samples_out = spp * 3 floats */) {
     using clock = std::chrono::steady_clock;
     const bool *kinds_present = sc_host_feat.kinds_present;
     auto t_begin = clock::now();
@@ -123,7 +125,13 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     if (re <= rb) { rb = 0; re = prm.height; }
     if (rb < 0 || re > prm.height) { err = "row band outside the film"; return PTRS_ERR_INVALID; }
     // sample rows (grid coordinates) whose footprint can touch output rows [rb, re)
-    const int32_t srow0 = std::max(rb, 0), srow1 = std::min(re + 4, g.NY);
+    int32_t srow0 = std::max(rb, 0), srow1 = std::min(re + 4, g.NY);
+    if (single_pixel) {
+        const int32_t sx = single_pixel[0] - g.min_x, sy = single_pixel[1] - g.min_y;
+        if (sx < 0 || sx >= g.NX || sy < 0 || sy >= g.NY) { err = "pixel outside the sample bounds"; return PTRS_ERR_INVALID; }
+        if (!samples_out) { err = "null argument"; return PTRS_ERR_INVALID; }
+        srow0 = sy; srow1 = sy + 1;
+    }
 
     DSampler S;
     S.matrices = be.sobol_matrices(); S.bytetab = be.sobol_bytetab(); S.nibtab = be.sobol_nibtab(); S.vdc = be.sobol_vdc(g.log2_res - 1); S.vdc_inv = be.sobol_vdc_inv(g.log2_res - 1);
@@ -149,6 +157,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     // end bounds it by its share of the memory that is free right now, so the library stays embeddable beside other users.
     uint64_t capacity = prm.paths_per_pass ? prm.paths_per_pass : std::min<uint64_t>(1ull << 27, be.auto_capacity(n_lanes, sc_host_feat.kinds_present));
     if (capacity < (uint64_t)g.NX) capacity = (uint64_t)g.NX;
+    if (single_pixel) capacity = std::max<uint64_t>(capacity, (uint64_t)g.NX * g.spp); // one pass: the pixel's spp paths (planned below as one row x all samples, launched as spp paths)
     const uint64_t band_rows = (uint64_t)(srow1 - srow0);
     uint64_t rows_per_pass, samples_per_pass;
     if (band_rows * (uint64_t)g.NX <= capacity) {
@@ -208,6 +217,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             be.select(lane);
             R.row0 = r0; R.row1 = r1; R.s0 = s0; R.s1 = s1;
             R.n_paths = (uint32_t)(r1 - r0) * (uint32_t)g.NX * (s1 - s0);
+            if (single_pixel) { R.pixel_mode = 1; R.pix_sx = single_pixel[0] - g.min_x; R.pix_sy = single_pixel[1] - g.min_y; R.n_paths = s1 - s0; }
             be.pass_begin(R);
             be.generate();
             uint32_t it = 0;
@@ -225,7 +235,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             }
             // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
             const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);
-            if (y1 > y0) be.film(film, y0, y1); // ordered after the previous pass's film kernel, whichever lane ran it
+            if (y1 > y0 && !single_pixel) be.film(film, y0, y1); // ordered after the previous pass's film kernel, whichever lane ran it
             if (samples_out) be.export_samples(samples_out);
             pending[lane].active = true; pending[lane].it = it; pending[lane].n_paths = R.n_paths;
         }

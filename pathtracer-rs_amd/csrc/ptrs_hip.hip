@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_samples(DParams R, DSampler S,
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < R.n_paths; pid += stride) {
         const PathCoord c = path_coord(R, S, pid);
-        const size_t o = (((size_t)c.sy * (size_t)R.NX + (size_t)c.sx) * S.spp + c.s) * 3;
+        const size_t o = R.pixel_mode ? (size_t)c.s * 3 : (((size_t)c.sy * (size_t)R.NX + (size_t)c.sx) * S.spp + c.s) * 3;
         const v4 L = P.L[pid];
         out[o] = L.x; out[o + 1] = L.y; out[o + 2] = L.z;
     }
@@ -1008,18 +1009,26 @@ struct HipBackend {
     }
 };
 
-int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm, v4 *film_dev, float *samples_dev, hipStream_t stream, PtrsStats *stats) {
-    if (!ps || !cam || !prm || !film_dev) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm, v4 *film_dev, float *samples_dev, hipStream_t stream, PtrsStats *stats, const int32_t *single_pixel = nullptr) {
+    if (!ps || !cam || !prm || (!film_dev && !single_pixel)) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     HIPCHK(hipSetDevice(ps->device));
     HipBackend be;
     be.ps = ps; be.stream = stream; be.opt = options();
     int rc = get_sobol(ps->device, &be.sob);
     if (rc != PTRS_OK) return rc;
     std::string err;
-    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err);
+    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err, single_pixel);
     if (rc != PTRS_OK) { if (!err.empty()) g_err = err; return rc; }
     if (be.rc != PTRS_OK) { if (g_err.empty()) g_err = "device error during render"; return be.rc; }
     return PTRS_OK;
+}
+
+// extern "C" entry points never let an exception (std::bad_alloc from a host vector, ...) cross the boundary
+template <class F> int guarded(F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { g_err = "out of host memory"; return PTRS_ERR_DEVICE; }
+    catch (const std::exception &e) { g_err = std::string("internal error: ") + e.what(); return PTRS_ERR_INVALID; }
+    catch (...) { g_err = "internal error"; return PTRS_ERR_INVALID; }
 }
 
 } // namespace
@@ -1061,7 +1070,9 @@ int ptrs_get_option(const char *name, int64_t *value) {
     return PTRS_ERR_INVALID;
 }
 
-int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out) {
+static int scene_create_impl(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out);
+int ptrs_scene_create(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out) { return guarded([&]() { return scene_create_impl(desc, device, out); }); }
+static int scene_create_impl(const PtrsSceneDesc *desc, int32_t device, PtrsScene **out) {
     if (!desc || !out) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (this library has no CPU fallback)"; return PTRS_ERR_DEVICE; }
@@ -1115,10 +1126,14 @@ int ptrs_scene_info(PtrsScene *scene, uint64_t *n_nodes, uint64_t *max_depth, ui
 }
 
 int ptrs_render_device(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, void *film_inout_device, void *hip_stream, PtrsStats *stats) {
-    return do_render(scene, camera, params, (v4 *)film_inout_device, nullptr, (hipStream_t)hip_stream, stats);
+    return guarded([&]() { return do_render(scene, camera, params, (v4 *)film_inout_device, nullptr, (hipStream_t)hip_stream, stats); });
 }
 
+static int render_samples_impl(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, float *sample_rgb, PtrsStats *stats);
 int ptrs_render_samples(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, float *sample_rgb, PtrsStats *stats) {
+    return guarded([&]() { return render_samples_impl(scene, camera, params, film_inout, sample_rgb, stats); });
+}
+static int render_samples_impl(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, float *sample_rgb, PtrsStats *stats) {
     if (!scene || !params || !film_inout) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     HIPCHK(hipSetDevice(scene->device));
     const size_t npx = (size_t)params->width * (size_t)params->height;
@@ -1145,25 +1160,30 @@ int ptrs_render(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderPara
 }
 
 int ptrs_render_single_pixel(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, int32_t px, int32_t py, float *rgb_out) {
-    // render_single_pixel (integrator.rs:505-534): run the one film row that holds the pixel and
-    // return that pixel's per-sample radiance.  Pixels in the filter apron outside the film rows
-    // are not reachable through a row band and are rejected.
-    if (!scene || !params || !rgb_out) { g_err = "null argument"; return PTRS_ERR_INVALID; }
-    if (px < -2 || px >= params->width + 2 || py < 0 || py >= params->height) { g_err = "pixel outside the film rows"; return PTRS_ERR_INVALID; }
-    const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
-    std::vector<PtrsFilmPixel> film((size_t)params->width * params->height);
-    std::memset(film.data(), 0, film.size() * sizeof(PtrsFilmPixel));
-    std::vector<float> samples((size_t)g.NX * g.NY * g.spp * 3);
-    PtrsRenderParams p = *params;
-    p.row_begin = py; p.row_end = py + 1;
-    int rc = ptrs_render_samples(scene, camera, &p, film.data(), samples.data(), nullptr);
-    if (rc != PTRS_OK) return rc;
-    const size_t o = (((size_t)(py - g.min_y) * g.NX + (size_t)(px - g.min_x)) * g.spp) * 3;
-    std::memcpy(rgb_out, samples.data() + o, (size_t)g.spp * 3 * sizeof(float));
-    return PTRS_OK;
+    // render_single_pixel (integrator.rs:505-534): the sampler is started on `pixel` and li() evaluated for each of its samples;
+    // the reference accepts any pixel (it never touches the film), here: any pixel of the sample bounds, apron included.  Only
+    // that pixel's spp paths are traced.
+    return guarded([&]() -> int {
+        if (!scene || !params || !rgb_out) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+        HIPCHK(hipSetDevice(scene->device));
+        const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
+        const size_t bytes = (size_t)g.spp * 3 * sizeof(float);
+        int rc = scene->samples_tmp.ensure(bytes);
+        if (rc != PTRS_OK) return rc;
+        HIPCHK(hipMemset(scene->samples_tmp.p, 0, bytes));
+        const int32_t pixel[2] = {px, py};
+        rc = do_render(scene, camera, params, nullptr, (float *)scene->samples_tmp.p, nullptr, nullptr, pixel);
+        if (rc != PTRS_OK) return rc;
+        HIPCHK(hipMemcpy(rgb_out, scene->samples_tmp.p, bytes, hipMemcpyDeviceToHost));
+        return PTRS_OK;
+    });
 }
 
+static int trace_rays_impl(PtrsScene *scene, uint32_t n, const float *rays, int32_t any_hit, PtrsHit *hits_out, PtrsStats *stats);
 int ptrs_trace_rays(PtrsScene *scene, uint32_t n, const float *rays, int32_t any_hit, PtrsHit *hits_out, PtrsStats *stats) {
+    return guarded([&]() { return trace_rays_impl(scene, n, rays, any_hit, hits_out, stats); });
+}
+static int trace_rays_impl(PtrsScene *scene, uint32_t n, const float *rays, int32_t any_hit, PtrsHit *hits_out, PtrsStats *stats) {
     if (!scene || (n && (!rays || !hits_out))) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     if (scene->H.max_depth > 64) { g_err = "BVH deeper than 64"; return PTRS_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(scene->device));

@@ -199,6 +199,7 @@ class PathIntegrator:
         p = self.params(camera)
         cam = camera.to_abi()
         out = np.zeros((round_up_pow2(p.spp), 3), dtype=np.float32)
+        self.last_single_pixel_paths = round_up_pow2(p.spp)
         _check(load_library().ptrs_render_single_pixel(ds.handle, C.byref(cam), C.byref(p), int(pixel[0]), int(pixel[1]), C.c_void_p(out.ctypes.data)))
         return out
 

@@ -122,7 +122,7 @@ struct HostBackend {
     void export_samples(float *out) {
         for (uint32_t pid = 0; pid < R.n_paths; ++pid) {
             PathCoord c = path_coord(R, S, pid);
-            size_t o = (((size_t)c.sy * (size_t)R.NX + (size_t)c.sx) * S.spp + c.s) * 3;
+            size_t o = R.pixel_mode ? (size_t)c.s * 3 : (((size_t)c.sy * (size_t)R.NX + (size_t)c.sx) * S.spp + c.s) * 3;
             out[o] = P.L[pid].x; out[o + 1] = P.L[pid].y; out[o + 2] = P.L[pid].z;
         }
     }

@@ -3,6 +3,8 @@ inputs.  Bars: bit-exact for integer work (Sobol indices, hit primitive ids, ray
 because host and device share one arithmetic definition -- also for every per-sample radiance;
 the film (a sum whose order the reference itself does not fix, film.rs:213-228) is held to
 1e-5 relative per-pixel L2 (north_star allows 1e-4)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -150,16 +152,16 @@ def test_stack_spill_path_matches_oracle(ptrs, orc, scenes):
 
 def test_traversal_kernel_variants_give_the_same_samples(ptrs, orc, scenes):
     """The options refill / refill_connect = 0 select the fused k_extend / k_connect instead of the lane-refill kernels
-    (+ k_epilogue / k_resolve), vote = 0 the while-while loop instead of phase voting; any combination and any idle-lane
-    threshold must give the same samples."""
+    (+ k_epilogue / k_resolve), vote = 0 the while-while loop instead of phase voting, shade_lds = 0 global-memory tables in
+    the shade kernels; any combination and any idle-lane threshold must give the same samples."""
     cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
-    for ext, con, vote in ((0, 0, 1), (1, 1, 1), (0, 16, 0), (64, 0, 1), (16, 16, 0), (16, 16, 1), (48, 48, 1)):
-        with ptrs.options(refill=ext, refill_connect=con, vote=vote):
+    for ext, con, vote, lds in ((0, 0, 1, 1), (1, 1, 1, 1), (0, 16, 0, 0), (64, 0, 1, 1), (16, 16, 0, 1), (16, 16, 1, 0), (48, 48, 1, 1)):
+        with ptrs.options(refill=ext, refill_connect=con, vote=vote, shade_lds=lds):
             _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
     # and on an LDS-resident (pair-form) scene
     cam, scene = ptrs.import_scene(CORNELL, (48, 48))
-    for ext, con, vote in ((0, 0, 1), (16, 16, 0), (16, 16, 1), (16, 0, 1)):
-        with ptrs.options(refill=ext, refill_connect=con, vote=vote):
+    for ext, con, vote, lds in ((0, 0, 1, 1), (16, 16, 0, 0), (16, 16, 1, 1), (16, 0, 1, 0), (16, 0, 0, 1)):
+        with ptrs.options(refill=ext, refill_connect=con, vote=vote, shade_lds=lds):
             _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
 
 
@@ -293,10 +295,13 @@ def test_render_single_pixel_on_the_gpu(ptrs, orc):
     integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(8, cam.film.get_sample_bounds()), 6)
     p = orc.make_params(40, 40, 8, 6)
     O = orc.OracleScene(scene)
-    for px, py in ((0, 0), (17, 23), (39, 39), (-2, 5), (41, 39)):  # incl. the filter apron left and right of the film rows
+    for px, py in ((0, 0), (17, 23), (39, 39), (-2, 5), (41, 39), (5, -2), (5, 41), (-2, -2), (41, 41)):  # incl. the filter apron on all four sides
         got = integ.render_single_pixel(cam, (px, py), scene)
         want = O.render_single_pixel(cam, p, px, py)
         assert np.array_equal(np.asarray(got).view(np.uint32), want.view(np.uint32))
+    assert integ.last_single_pixel_paths == 8  # only the pixel's spp paths were traced
+    with pytest.raises(ptrs.PtrsError):  # outside the sample bounds
+        integ.render_single_pixel(cam, (42, 0), scene)
 
 
 def test_cfg5_band_with_33_bit_sobol_indices(ptrs, orc, scenes):
@@ -316,6 +321,57 @@ def test_cfg5_band_with_33_bit_sobol_indices(ptrs, orc, scenes):
     assert (b["weight"] > 0).all()
     # 12 800 binary32 additions per pixel in two different orders (the reference's own order depends on tile scheduling)
     assert np.allclose(a["weight"], b["weight"], rtol=1e-4) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-4
+
+
+def _band_vs_fixture(ptrs, cam, scene, spp, name):
+    """Rows of a full-settings render against the oracle fixture tests/golden/bench_<name>_rows.npz (made by make_golden.py --bench):
+    ray counts of the band identical, film rows within the tolerance of two summation orders."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_%s_rows.npz" % name))
+    rb, re = int(z["row0"]), int(z["row1"])
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(spp, cam.film.get_sample_bounds()), 15)
+    integ.render(cam, scene, row_begin=rb, row_end=re)
+    st = integ.last_stats
+    assert (st.rays_extension, st.rays_shadow, st.rays_mis, st.samples) == tuple(int(v) for v in z["rays"])
+    a = cam.film.pixels[rb:re]
+    got = np.concatenate([a["rgb"], a["weight"][..., None]], axis=-1)
+    ref = z["film"]
+    assert np.allclose(got[..., 3], ref[..., 3], rtol=1e-4)
+    assert rel_l2(got[..., :3] / got[..., 3:], ref[..., :3] / ref[..., 3:]) < 1e-4
+
+
+def test_cfg3_colonnade_band_at_full_settings(ptrs, scenes):
+    """BASELINE configs[2] settings (1280x720, 64 spp, depth 15) on the 262 k-triangle colonnade stand-in, rows 358-360."""
+    cam, scene = scenes.colonnade((1280, 720))
+    _band_vs_fixture(ptrs, cam, scene, 64, "colonnade")
+
+
+def test_cfg4_classroom_band_at_full_settings(ptrs, scenes):
+    """BASELINE configs[3] settings (1920x1080, 128 spp, depth 15) on the 606 k-triangle classroom stand-in lit by
+    data/abandoned_tank_farm_04_1k.hdr (the map the config names), rows 540-542."""
+    cam, scene = scenes.classroom((1920, 1080))
+    _band_vs_fixture(ptrs, cam, scene, 128, "classroom")
+
+
+def test_sobol_dimension_overrun_is_an_error(ptrs):
+    """The reference panics when a sample needs Sobol dimension >= 1024 (sobol.rs:177-183); a matte vertex draws 8, so a
+    path deeper than ~127 bounces gets there.  Closed white box, Russian roulette off, max_depth 200: render must fail with
+    PTRS_ERR_UNSUPPORTED instead of reading past the table (and succeed at a depth that stays inside it)."""
+    s = ptrs.RenderScene()
+    white = s.add_material(ptrs.abi.MAT_MATTE, [s.const_rgb([1.0, 1.0, 1.0])])
+    from importlib import import_module
+    sc = import_module("pathtracer-rs_amd.scene")
+    pos, nrm, idx = sc.gen_cube()
+    s.add_mesh((pos * np.float32(2.0)).astype(np.float32), idx, white, normal=(-nrm).astype(np.float32))
+    s.add_point_light([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    cam = ptrs.look_at_camera([0.5, 0.3, 1.0], [0.0, 0.0, -1.0], [0, 1, 0], 60.0, (16, 16))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(1, cam.film.get_sample_bounds()), 200)
+    integ.rr_enable = False
+    with pytest.raises(ptrs.PtrsError, match="1024 dimensions"):
+        integ.render(cam, s)
+    ok = ptrs.PathIntegrator(ptrs.SamplerBuilder(1, cam.film.get_sample_bounds()), 100)
+    ok.rr_enable = False
+    ok.render(cam, s)
+    assert ok.last_stats.rays_extension > 16 * 16 * 90
 
 
 def test_cfg2_band_at_full_settings(ptrs, orc):
