@@ -241,6 +241,17 @@ int ptrs_scene_info(PtrsScene *scene, uint64_t *n_nodes, uint64_t *max_depth, ui
 int ptrs_render(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params,
                 PtrsFilmPixel *film_inout, PtrsStats *stats);
 
+/* One process, several devices (the reference host is one process: main.rs:101-126).  scenes[i] is the same scene
+ * created on device i (ptrs_scene_create with that ordinal); output rows [band_bounds[i], band_bounds[i+1]) are rendered
+ * by scenes[i] on a host thread of its own, gathered into scenes[0]'s device with peer copies and returned in
+ * film_inout (host, ACCUMULATED like ptrs_render).  band_bounds: n+1 row numbers from 0 to height, or NULL for equal
+ * bands; ptrs_plan_bands computes them, optionally weighted by a per-row cost (row_cost[height], e.g. ray counts of
+ * a 1-spp probe; NULL = equal rows).  stats_per_scene: n records or NULL.  Bit-identical to ptrs_render. */
+int ptrs_plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_t *bounds_out /* n + 1 */);
+int ptrs_render_multi(PtrsScene *const *scenes, uint32_t n, const PtrsCamera *camera,
+                      const PtrsRenderParams *params, const int32_t *band_bounds,
+                      PtrsFilmPixel *film_inout, PtrsStats *stats_per_scene);
+
 /* Same, but the film lives in DEVICE memory (width*height PtrsFilmPixel) and the work is queued
  * on `hip_stream` (a hipStream_t, NULL = default stream); returns after the stream has drained.
  * This is what bench.py times and what the multi-GPU gather reads. */

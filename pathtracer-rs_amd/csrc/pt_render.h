@@ -12,8 +12,10 @@
 // `BE` is the execution back end: the HIP back end (ptrs_hip.hip) launches gfx950 kernels; the
 // test-only host twin (tests/host_twin) runs the same stage functions serially on the CPU.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <vector>
 
 #include "pt_host_scene.h"
 #include "pt_items.h"
@@ -107,6 +109,32 @@ inline int scene_trace_features(const HostScene &H) {
     bool any = !H.inf_lights.empty() || H.has_alpha;
     for (const DLight &L : H.lights) any = any || (L.kind == PTRS_LIGHT_AREA && !L.ke_const);
     return any ? FEAT_FULL : FEAT_SIMPLE;
+}
+
+// Output-row bands for n devices: bounds[0] = 0 <= bounds[1] <= ... <= bounds[n] = height.  Without costs the
+// rows are split as evenly as possible (earlier bands take the remainder); with a per-row cost (e.g. rays of a 1-spp
+// probe) band k ends at the first row where the running cost reaches k/n of the total -- every band keeps at least one
+// row while rows remain.  A band's device also traces the 2-row filter halo on each side (film.rs:60-106), which is
+// not part of its cost here.
+inline void plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_t *bounds) {
+    bounds[0] = 0; bounds[n] = height;
+    std::vector<double> pre((size_t)height + 1, 0.0); // pre[y] = cost of rows [0, y)
+    if (row_cost) for (int32_t y = 0; y < height; ++y) pre[(size_t)y + 1] = pre[(size_t)y] + (row_cost[y] > 0.0f ? (double)row_cost[y] : 0.0);
+    const double total = pre[(size_t)height];
+    if (!row_cost || !(total > 0.0)) {
+        const int32_t base = height / (int32_t)n, rem = height % (int32_t)n;
+        for (uint32_t k = 1; k < n; ++k) bounds[k] = (int32_t)k * base + std::min<int32_t>((int32_t)k, rem);
+        return;
+    }
+    for (uint32_t k = 1; k < n; ++k) {
+        const double target = total * (double)k / (double)n;
+        int32_t y = (int32_t)(std::upper_bound(pre.begin(), pre.end(), target) - pre.begin()) - 1; // most rows whose cost stays <= target
+        // of the two cuts around the target take the closer one
+        if (y < height && pre[(size_t)y + 1] - target < target - pre[(size_t)y]) ++y;
+        const int32_t lo = std::min<int32_t>(bounds[k - 1] + 1, height);            // at least one row per band while rows remain ...
+        const int32_t hi = std::max<int32_t>(lo, height - (int32_t)(n - k));        // ... also for the bands after this one
+        bounds[k] = std::min(std::max(y, lo), hi);
+    }
 }
 
 template <class BE>

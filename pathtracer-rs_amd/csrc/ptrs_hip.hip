@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pt_render.h"
@@ -1139,7 +1140,13 @@ static int render_samples_impl(PtrsScene *scene, const PtrsCamera *camera, const
     const size_t npx = (size_t)params->width * (size_t)params->height;
     int rc = scene->film_tmp.ensure(npx * sizeof(PtrsFilmPixel));
     if (rc != PTRS_OK) return rc;
-    HIPCHK(hipMemcpy(scene->film_tmp.p, film_inout, npx * sizeof(PtrsFilmPixel), hipMemcpyHostToDevice));
+    // only the rows of the band travel (rows outside [row_begin, row_end) are untouched: concurrent renders of disjoint
+    // bands into one host film, one per device, do not step on each other)
+    int32_t rb = params->row_begin, re = params->row_end;
+    if (re <= rb) { rb = 0; re = params->height; }
+    if (rb < 0 || re > params->height) { g_err = "row band outside the film"; return PTRS_ERR_INVALID; }
+    const size_t band_off = (size_t)rb * (size_t)params->width, band_px = (size_t)(re - rb) * (size_t)params->width;
+    HIPCHK(hipMemcpy((PtrsFilmPixel *)scene->film_tmp.p + band_off, film_inout + band_off, band_px * sizeof(PtrsFilmPixel), hipMemcpyHostToDevice));
     float *sdev = nullptr; size_t sbytes = 0;
     if (sample_rgb) {
         const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
@@ -1150,13 +1157,78 @@ static int render_samples_impl(PtrsScene *scene, const PtrsCamera *camera, const
     }
     rc = do_render(scene, camera, params, (v4 *)scene->film_tmp.p, sdev, nullptr, stats);
     if (rc != PTRS_OK) return rc;
-    HIPCHK(hipMemcpy(film_inout, scene->film_tmp.p, npx * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(film_inout + band_off, (PtrsFilmPixel *)scene->film_tmp.p + band_off, band_px * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost));
     if (sample_rgb) HIPCHK(hipMemcpy(sample_rgb, sdev, sbytes, hipMemcpyDeviceToHost));
     return PTRS_OK;
 }
 
 int ptrs_render(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, PtrsStats *stats) {
     return ptrs_render_samples(scene, camera, params, film_inout, nullptr, stats);
+}
+
+// ---- one process, N devices ---------------------------------------------------------------------------
+int ptrs_plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_t *bounds_out) {
+    if (height <= 0 || n == 0 || !bounds_out) { g_err = "bad band request"; return PTRS_ERR_INVALID; }
+    return guarded([&]() -> int { plan_bands(height, n, row_cost, bounds_out); return PTRS_OK; });
+}
+
+int ptrs_render_multi(PtrsScene *const *scenes, uint32_t n, const PtrsCamera *camera, const PtrsRenderParams *params, const int32_t *band_bounds,
+                      PtrsFilmPixel *film_inout, PtrsStats *stats_per_scene) {
+    return guarded([&]() -> int {
+        if (!scenes || n == 0 || !camera || !params || !film_inout) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+        for (uint32_t i = 0; i < n; ++i) if (!scenes[i]) { g_err = "null scene"; return PTRS_ERR_INVALID; }
+        const int32_t H = params->height, W = params->width;
+        std::vector<int32_t> bounds(n + 1);
+        if (band_bounds) { bounds.assign(band_bounds, band_bounds + n + 1); }
+        else plan_bands(H, n, nullptr, bounds.data());
+        if (bounds[0] != 0 || bounds[n] != H) { g_err = "band bounds must run from 0 to height"; return PTRS_ERR_INVALID; }
+        for (uint32_t i = 0; i < n; ++i) if (bounds[i + 1] < bounds[i]) { g_err = "band bounds must not decrease"; return PTRS_ERR_INVALID; }
+        // Each device renders its band into a film of its own; the bands are then gathered into device 0's film with peer
+        // copies over xGMI (hipMemcpyPeer; staged through the host where two devices cannot reach each other) and leave
+        // through one device-to-host copy.  Rows are disjoint and every sample's value depends only on (pixel, sample
+        // index), so the result is bit-identical to ptrs_render on one device.
+        const size_t npx = (size_t)W * (size_t)H;
+        std::vector<int> rcs(n, PTRS_OK); std::vector<std::string> errs(n);
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < n; ++i) {
+            th.emplace_back([&, i]() {
+                PtrsScene *ps = scenes[i];
+                rcs[i] = guarded([&]() -> int {
+                    if (bounds[i + 1] == bounds[i]) { if (stats_per_scene) std::memset(&stats_per_scene[i], 0, sizeof(PtrsStats)); return PTRS_OK; }
+                    HIPCHK(hipSetDevice(ps->device));
+                    int rc = ps->film_tmp.ensure(npx * sizeof(PtrsFilmPixel));
+                    if (rc != PTRS_OK) return rc;
+                    const size_t off = (size_t)bounds[i] * W, cnt = (size_t)(bounds[i + 1] - bounds[i]) * W;
+                    HIPCHK(hipMemcpy((PtrsFilmPixel *)ps->film_tmp.p + off, film_inout + off, cnt * sizeof(PtrsFilmPixel), hipMemcpyHostToDevice));
+                    PtrsRenderParams p = *params;
+                    p.row_begin = bounds[i]; p.row_end = bounds[i + 1]; p.device = ps->device;
+                    return do_render(ps, camera, &p, (v4 *)ps->film_tmp.p, nullptr, nullptr, stats_per_scene ? &stats_per_scene[i] : nullptr);
+                });
+                if (rcs[i] != PTRS_OK) errs[i] = g_err; // thread-local message of the worker
+            });
+        }
+        for (auto &t : th) t.join();
+        for (uint32_t i = 0; i < n; ++i) if (rcs[i] != PTRS_OK) { g_err = "device " + std::to_string(scenes[i]->device) + ": " + errs[i]; return rcs[i]; }
+        PtrsScene *root = scenes[0];
+        HIPCHK(hipSetDevice(root->device));
+        int rc = root->film_tmp.ensure(npx * sizeof(PtrsFilmPixel));
+        if (rc != PTRS_OK) return rc;
+        for (uint32_t i = 1; i < n; ++i) {
+            const size_t off = (size_t)bounds[i] * W, bytes = (size_t)(bounds[i + 1] - bounds[i]) * W * sizeof(PtrsFilmPixel);
+            if (!bytes || scenes[i] == root) continue;
+            PtrsFilmPixel *dst = (PtrsFilmPixel *)root->film_tmp.p + off; const PtrsFilmPixel *src = (const PtrsFilmPixel *)scenes[i]->film_tmp.p + off;
+            hipError_t e = scenes[i]->device == root->device ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, root->device, src, scenes[i]->device, bytes);
+            if (e != hipSuccess) { // no peer path: through the host film
+                (void)hipGetLastError();
+                HIPCHK(hipSetDevice(scenes[i]->device));
+                HIPCHK(hipMemcpy(film_inout + off, src, bytes, hipMemcpyDeviceToHost));
+                HIPCHK(hipSetDevice(root->device));
+                HIPCHK(hipMemcpy(dst, film_inout + off, bytes, hipMemcpyHostToDevice));
+            }
+        }
+        HIPCHK(hipMemcpy(film_inout, root->film_tmp.p, npx * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost));
+        return PTRS_OK;
+    });
 }
 
 int ptrs_render_single_pixel(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, int32_t px, int32_t py, float *rgb_out) {

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "ptrs_host.hpp"
 
@@ -24,7 +25,8 @@ static bool parse_resolution(const char *s, int &w, int &h) { // main.rs:23-33
 
 int main(int argc, char **argv) {
     std::string scene_path, out_dir, dump_path, dump_full_path, env_map_path;
-    bool default_lights = false;
+    bool default_lights = false, even_bands = false;
+    int n_gpus = 1;
     int spp = 1, max_depth = 15, w = 640, h = 480; // DEFAULT_RESOLUTION common/mod.rs:14
     bool have_out = false;
     for (int i = 1; i < argc; ++i) {
@@ -38,13 +40,15 @@ int main(int argc, char **argv) {
         else if (a == "--dump-scene-full") dump_full_path = need("--dump-scene-full");
         else if (a == "--default_lights") default_lights = true; // main.rs:48,99
         else if (a == "--env_map") env_map_path = need("--env_map"); // the Radiance .hdr --default_lights uses (the reference's bundled file is not shipped)
+        else if (a == "--gpus") n_gpus = std::atoi(need("--gpus")); // not a flag of the reference: split the frame's rows over N devices of this process
+        else if (a == "--even_bands") even_bands = true;               // equal-height bands instead of the 1-spp cost probe
         else if (a == "--headless") {}
         else if (a == "-c" || a == "--camera" || a == "-l" || a == "--log_level" || a == "-m" || a == "--module_log" || a == "--server") (void)need(a.c_str());
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "error: unknown flag %s\n", a.c_str()); return 2; }
         else scene_path = a;
     }
     if (scene_path.empty() || (!have_out && dump_path.empty() && dump_full_path.empty())) {
-        std::fprintf(stderr, "usage: ptrs_headless SCENE(.xml|.gltf|.glb) -o DIR [-s SPP] [-r WxH] [-d DEPTH] [--default_lights --env_map FILE.hdr] [--headless]\n");
+        std::fprintf(stderr, "usage: ptrs_headless SCENE(.xml|.gltf|.glb) -o DIR [-s SPP] [-r WxH] [-d DEPTH] [--default_lights --env_map FILE.hdr] [--gpus N [--even_bands]] [--headless]\n");
         return 2;
     }
     Camera camera; RenderScene scene; std::string err;
@@ -57,7 +61,16 @@ int main(int argc, char **argv) {
     integrator.preprocess(scene);
     PtrsStats st{};
     auto t0 = std::chrono::steady_clock::now();
-    int rc = integrator.render(camera, scene, &st);
+    int rc;
+    if (n_gpus > 1) {
+        std::vector<PtrsStats> sts((size_t)n_gpus);
+        std::vector<int32_t> bands;
+        rc = integrator.render_multi(camera, scene, n_gpus, !even_bands, sts.data(), &bands);
+        for (int d = 0; rc == PTRS_OK && d < n_gpus; ++d) {
+            std::fprintf(stderr, "INFO device %d: rows %d..%d, %llu rays\n", d, bands[(size_t)d], bands[(size_t)d + 1], (unsigned long long)(sts[(size_t)d].rays_extension + sts[(size_t)d].rays_shadow + sts[(size_t)d].rays_mis));
+            st.samples += sts[(size_t)d].samples; st.rays_extension += sts[(size_t)d].rays_extension; st.rays_shadow += sts[(size_t)d].rays_shadow; st.rays_mis += sts[(size_t)d].rays_mis;
+        }
+    } else rc = integrator.render(camera, scene, &st);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != PTRS_OK) { std::fprintf(stderr, "error: render failed (%d): %s\n", rc, integrator.last_error.c_str()); return 1; }
     std::fprintf(stderr, "INFO rendering took: %.3fs (%llu samples, %llu rays, %.1f Mray/s)\n", secs, (unsigned long long)st.samples,

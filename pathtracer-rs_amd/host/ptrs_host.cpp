@@ -80,9 +80,19 @@ SamplerBuilder::SamplerBuilder(int spp, const int32_t bounds[4]) {
 }
 PathIntegrator::PathIntegrator(const SamplerBuilder &sb, int max_depth, bool show_progress_bar, int device)
     : sb_(sb), max_depth_(max_depth), show_progress_bar_(show_progress_bar), device_(device) {}
-PathIntegrator::~PathIntegrator() { if (gpu_scene_) ptrs_scene_destroy(gpu_scene_); }
+PathIntegrator::~PathIntegrator() {
+    if (gpu_scene_) ptrs_scene_destroy(gpu_scene_);
+    for (PtrsScene *s : multi_scenes_) if (s) ptrs_scene_destroy(s);
+}
 void PathIntegrator::preprocess(const RenderScene &scene) {
     if (scene.lights.size() > 16) std::fprintf(stderr, "WARN scene contains too many lights for path integrator to handle well\n");
+}
+PtrsRenderParams PathIntegrator::params(const Camera &camera) const {
+    PtrsRenderParams p{};
+    p.width = camera.film.width; p.height = camera.film.height; p.spp = sb_.samples_per_pixel; p.max_depth = max_depth_;
+    p.rr_threshold = rr_threshold_; p.rr_start_depth = rr_start_depth_; p.rr_enable = rr_enable_ ? 1 : 0;
+    p.row_begin = 0; p.row_end = camera.film.height; p.device = device_; p.paths_per_pass = 0; p.flags = 0;
+    return p;
 }
 int PathIntegrator::render(Camera &camera, RenderScene &scene, PtrsStats *stats) {
     if (!gpu_scene_ || gpu_scene_src_ != &scene) {
@@ -91,11 +101,49 @@ int PathIntegrator::render(Camera &camera, RenderScene &scene, PtrsStats *stats)
         if (rc != PTRS_OK) { last_error = ptrs_last_error(); return rc; }
         gpu_scene_src_ = &scene;
     }
-    PtrsRenderParams p{};
-    p.width = camera.film.width; p.height = camera.film.height; p.spp = sb_.samples_per_pixel; p.max_depth = max_depth_;
-    p.rr_threshold = rr_threshold_; p.rr_start_depth = rr_start_depth_; p.rr_enable = rr_enable_ ? 1 : 0;
-    p.row_begin = 0; p.row_end = camera.film.height; p.device = device_; p.paths_per_pass = 0; p.flags = 0;
+    const PtrsRenderParams p = params(camera);
     int rc = ptrs_render(gpu_scene_, &camera.abi, &p, camera.film.pixels.data(), stats);
+    if (rc != PTRS_OK) last_error = ptrs_last_error();
+    return rc;
+}
+
+bool probe_row_cost(PtrsScene *scene, const PtrsCamera &camera, const PtrsRenderParams &params, int strips, std::vector<float> &row_cost, std::string &err) {
+    const int H = params.height;
+    strips = std::max(1, std::min(strips, H));
+    row_cost.assign((size_t)H, 0.0f);
+    std::vector<PtrsFilmPixel> scratch((size_t)params.width * (size_t)H, PtrsFilmPixel{{0, 0, 0}, 0});
+    PtrsRenderParams p = params;
+    p.spp = 1;
+    for (int k = 0; k < strips; ++k) {
+        p.row_begin = (int)((long long)H * k / strips); p.row_end = (int)((long long)H * (k + 1) / strips);
+        if (p.row_end <= p.row_begin) continue;
+        PtrsStats st{};
+        if (ptrs_render(scene, &camera, &p, scratch.data(), &st) != PTRS_OK) { err = ptrs_last_error(); return false; }
+        const float per_row = (float)((double)(st.rays_extension + st.rays_shadow + st.rays_mis) / (double)(p.row_end - p.row_begin));
+        for (int y = p.row_begin; y < p.row_end; ++y) row_cost[(size_t)y] = per_row;
+    }
+    return true;
+}
+
+int PathIntegrator::render_multi(Camera &camera, RenderScene &scene, int n_devices, bool cost_weighted, PtrsStats *stats, std::vector<int32_t> *bands_out) {
+    if (n_devices < 1) { last_error = "render_multi needs at least one device"; return PTRS_ERR_INVALID; }
+    if (multi_src_ != &scene || (int)multi_scenes_.size() != n_devices) {
+        for (PtrsScene *s : multi_scenes_) if (s) ptrs_scene_destroy(s);
+        multi_scenes_.assign((size_t)n_devices, nullptr);
+        for (int d = 0; d < n_devices; ++d) { // the scene is replicated: every device walks the whole BVH for its band
+            int rc = ptrs_scene_create(&scene.desc(), d, &multi_scenes_[(size_t)d]);
+            if (rc != PTRS_OK) { last_error = std::string("device ") + std::to_string(d) + ": " + ptrs_last_error(); return rc; }
+        }
+        multi_src_ = &scene;
+    }
+    const PtrsRenderParams p = params(camera);
+    std::vector<int32_t> bounds((size_t)n_devices + 1);
+    std::vector<float> cost;
+    if (cost_weighted && n_devices > 1 && !probe_row_cost(multi_scenes_[0], camera.abi, p, 64, cost, last_error)) return PTRS_ERR_DEVICE;
+    int rc = ptrs_plan_bands(p.height, (uint32_t)n_devices, cost.empty() ? nullptr : cost.data(), bounds.data());
+    if (rc != PTRS_OK) { last_error = ptrs_last_error(); return rc; }
+    if (bands_out) *bands_out = bounds;
+    rc = ptrs_render_multi(multi_scenes_.data(), (uint32_t)n_devices, &camera.abi, &p, bounds.data(), camera.film.pixels.data(), stats);
     if (rc != PTRS_OK) last_error = ptrs_last_error();
     return rc;
 }

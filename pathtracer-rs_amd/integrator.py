@@ -194,6 +194,30 @@ class PathIntegrator:
         self.last_stats = stats
         return stats
 
+    def render_multi(self, camera, scene, devices, bounds=None, row_cost=None):
+        """ptrs_render_multi: the frame's rows split over `devices` (one PtrsScene per entry, one host thread each, bands
+        gathered on the first device); bounds = n+1 row numbers, or planned by ptrs_plan_bands (weighted by row_cost when
+        given).  Accumulates into camera.film.pixels; returns (bounds, [PtrsStats per device])."""
+        L = load_library()
+        n = len(devices)
+        scenes = [_DeviceScene(scene, d) for d in devices]  # fresh replicas, also when several share a device
+        try:
+            p = self.params(camera)
+            cam = camera.to_abi()
+            b = (C.c_int32 * (n + 1))()
+            if bounds is None:
+                rc = None if row_cost is None else np.ascontiguousarray(row_cost, dtype=np.float32)
+                _check(L.ptrs_plan_bands(p.height, n, C.c_void_p(rc.ctypes.data) if rc is not None else None, b))
+            else:
+                b[:] = [int(v) for v in bounds]
+            handles = (C.c_void_p * n)(*[s.handle for s in scenes])
+            stats = (abi.PtrsStats * n)()
+            _check(L.ptrs_render_multi(handles, n, C.byref(cam), C.byref(p), b, C.c_void_p(camera.film.pixels.ctypes.data), stats))
+            return list(b), list(stats)
+        finally:
+            for s in scenes:
+                s.close()
+
     def render_single_pixel(self, camera, pixel, scene):  # integrator.rs:505-534
         ds = _device_scene(scene, self.device)
         p = self.params(camera)

@@ -352,6 +352,26 @@ def test_cfg4_classroom_band_at_full_settings(ptrs, scenes):
     _band_vs_fixture(ptrs, cam, scene, 128, "classroom")
 
 
+def test_multi_device_render_is_bit_identical(ptrs):
+    """ptrs_render_multi (one process, one host thread and one scene replica per device, bands gathered with device
+    copies): 2 and 3 replicas -- all on the one GPU of this box -- with equal and with cost-weighted bands must reproduce
+    the single-device film bit for bit, and the bands' ray counts (minus the re-traced halo rows) must add up."""
+    cam, scene = ptrs.import_scene(CORNELL, (96, 80))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(16, cam.film.get_sample_bounds()), 8)
+    integ.render(cam, scene)
+    ref = cam.film.pixels.copy()
+    for n, cost in ((2, None), (3, None), (3, np.linspace(1.0, 4.0, 80)), (4, np.r_[np.zeros(40), np.ones(40)])):
+        cam.film.clear()
+        bounds, stats = integ.render_multi(cam, scene, [0] * n, row_cost=cost)
+        assert bounds[0] == 0 and bounds[-1] == 80 and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
+        assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+        assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), ref["weight"].view(np.uint32))
+        traced = sum((b1 - b0 + 4) for b0, b1 in zip(bounds, bounds[1:]) if b1 > b0)
+        assert sum(st.samples for st in stats) == traced * 100 * 16  # each band traces its rows + 4 sample rows of apron / halo
+    if cost is not None:
+        assert bounds != [0, 20, 40, 60, 80]  # the weighted plan differs from equal bands
+
+
 def test_sobol_dimension_overrun_is_an_error(ptrs):
     """The reference panics when a sample needs Sobol dimension >= 1024 (sobol.rs:177-183); a matte vertex draws 8, so a
     path deeper than ~127 bounces gets there.  Closed white box, Russian roulette off, max_depth 200: render must fail with

@@ -71,6 +71,18 @@ def test_cpp_import_matches_python_import(cli, ptrs, tmp_path, res):
     assert [(l[0], l[1], l[2], _i32(l[3])) for l in lights] == [(l["kind"], l["mesh"], l["tri"], l["ke_tex"]) for l in scene.lights]
 
 
+def test_band_planning_cpp_unit(ptrs, tmp_path):
+    """tests/cpp/test_bands.cpp: ptrs_plan_bands through the C ABI from C++ (equal and cost-weighted row bands for the
+    N-device render).  CPU only."""
+    ptrs.load_library()
+    exe = str(tmp_path / "test_bands")
+    lib_dir = os.path.join(ROOT, "pathtracer-rs_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_bands.cpp"), "-L" + lib_dir, "-lptrs_hip", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "band planning ok" in out.stdout
+
+
 def test_cli_usage_and_errors(cli, tmp_path):
     assert subprocess.run([cli], capture_output=True).returncode == 2
     r = subprocess.run([cli, str(tmp_path / "missing.xml"), "-o", str(tmp_path)], capture_output=True, text=True)
