@@ -152,7 +152,7 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     if (sc.n_nodes2 + sc.n_nodes4 == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
-    const RayShear shear = ray_shear(d);
+    const RayShear shear = ray_shear_inv(d, inv);
     uint32_t cur = 0; // reference to process next (interior index or leaf), REF_NONE when done
     bool hit = false;
     while (cur != REF_NONE) {
@@ -215,7 +215,7 @@ PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     if (sc.n_nodes2 + sc.n_nodes4 == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
-    const RayShear shear = ray_shear(d);
+    const RayShear shear = ray_shear_inv(d, inv);
     uint32_t cur = 0;
     bool hit = false;
     while (cur != REF_NONE) {

@@ -74,6 +74,17 @@ PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2,
     h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
     return true;
 }
+// The same with 1/d already at hand (traversal computes it for the slab tests): sz = 1/d[kz] is one of its components --
+// the same division, so the same bits -- which saves one of the six IEEE divisions of a ray's set-up.
+PT_HD RayShear ray_shear_inv(f3 d, f3 inv) {
+    RayShear S;
+    S.kz = max_dimension(abs3(d));
+    int kx = S.kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    const float dx = comp(d, kx), dy = comp(d, ky), dz = comp(d, S.kz);
+    S.sx = -dx / dz; S.sy = -dy / dz; S.sz = comp(inv, S.kz);
+    return S;
+}
 PT_HD bool tri_test(f3 o, f3 d, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) { return tri_test_s(o, ray_shear(d), t_max, p0, p1, p2, h); }
 
 // triangle partial derivatives, shape.rs:187-215.  Returns false for a degenerate triangle.

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpi
 #define RF_DECL f3 r_o = mk3(0, 0, 0), r_inv = mk3(1, 1, 1); bool r_neg[3] = {false, false, false}; RayShear r_shear; r_shear.kz = 2; r_shear.sx = r_shear.sy = 0.0f; r_shear.sz = 1.0f; \
                 float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE;
 #define RF_START(O, D, TMAX) { r_o = (O); const f3 d_ = (D); r_tmax = (TMAX); r_inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); \
-                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_shear = ray_shear(d_); \
+                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_shear = ray_shear_inv(d_, r_inv); \
                 r_h.prim = -1; r_h.t = r_tmax; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; r_hit = false; r_cur = 0; }
 // next index of the workgroup's segment for every idle lane of the wave (one LDS atomic per wave)
 __device__ inline uint32_t rf_take(uint32_t *cursor, unsigned long long idle) {
@@ -246,25 +246,37 @@ __device__ inline uint32_t rf_take(uint32_t *cursor, unsigned long long idle) {
 // does: every descending lane reaches a leaf), so at least half of the lanes holding rays work in every step.  Each ray still
 // makes exactly the visits and tests of the while-while loop in the same order: results are identical.
 // (Measured, single lane, VALU lanes active per instruction / ms per frame: see DESIGN.md section 4.)
-struct StepCount { uint32_t node_steps = 0, node_visits = 0, tri_steps = 0; }; // counters_on only: steps count 64 per wave-level step (added by the wave's first active lane)
+// Diagnostic builds (-DPTRS_STEP_COUNTERS, tools/ablate.sh + tools/occupancy.py) count the wave-level node / triangle steps
+// and the lanes that took part in them (64 per step, added by the wave's first active lane); the product carries none of it.
+struct StepCount { uint32_t node_steps = 0, node_visits = 0, tri_steps = 0; };
+#ifdef PTRS_STEP_COUNTERS
 __device__ inline uint32_t first_lane_64() { return (int)__lane_id() == __ffsll((long long)__ballot(true)) - 1 ? 64u : 0u; }
+#define PT_COUNT_NODE(c) { (c).node_steps += first_lane_64(); ++(c).node_visits; }
+#define PT_COUNT_TRI(c, k) { (c).tri_steps += first_lane_64() * (k); }
+#else
+#define PT_COUNT_NODE(c)
+#define PT_COUNT_TRI(c, k)
+#endif
 template <bool VOTE, bool QUAD, bool ALPHA, class Stack, class Geom>
 __device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
-                               Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt, bool count, StepCount &sc_n) {
+                               Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt, StepCount &sc_n) {
     if (VOTE) {
-        const bool at_node = r_cur != REF_NONE && !(r_cur & REF_LEAF), at_leaf = r_cur != REF_NONE && (r_cur & REF_LEAF); // lanes without a ray hold REF_NONE
-        if (__popcll(__ballot(at_node)) >= __popcll(__ballot(at_leaf))) {
-            if (at_node) { if (count) { sc_n.node_steps += first_lane_64(); ++sc_n.node_visits; } node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
+        const bool at_node = (int32_t)r_cur >= 0, at_leaf = r_cur != REF_NONE && (int32_t)r_cur < 0; // leaf references have bit 31 set; lanes without a ray hold REF_NONE
+        const int n_node = __builtin_popcountll(__ballot(at_node)), n_leaf = __builtin_popcountll(__ballot(at_leaf));
+        if (n_node >= n_leaf) {
+            if (at_node) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
         } else if (at_leaf) {
-            if (count) sc_n.tri_steps += first_lane_64();
+            PT_COUNT_TRI(sc_n, 1u)
             const bool done = leaf_step<ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt);
             if (done) r_cur = REF_NONE; else if (r_cur == REF_NONE) r_cur = pop_next_ref<false>(stk, r_tmax);
         }
         return;
     }
-    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { if (count) { sc_n.node_steps += first_lane_64(); ++sc_n.node_visits; } node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
+    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
     if (r_cur != REF_NONE) {
-        if (count) { const uint32_t k = ((r_cur >> REF_COUNT_SHIFT) & 15u) + 1u; uint32_t kmax = k; for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kmax, off); kmax = o > kmax ? o : kmax; } sc_n.tri_steps += first_lane_64() * kmax; } // (lanes outside this branch contribute their stale k: an upper bound, diagnostic only)
+#ifdef PTRS_STEP_COUNTERS
+        { const uint32_t k = ((r_cur >> REF_COUNT_SHIFT) & 15u) + 1u; uint32_t kmax = k; for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kmax, off); kmax = o > kmax ? o : kmax; } PT_COUNT_TRI(sc_n, kmax) } // (an upper bound, diagnostic only)
+#endif
         const bool done = leaf_test<false, ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt); r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax);
     }
 }
@@ -308,9 +320,12 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
         }
         if (!__any(has)) break; // every ray of the segment this wave could get is retired
         do { // steps until a lane finishes its ray: only then is there something to retire or refill
-            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, R.counters_on != 0, stepc);
-            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, R.counters_on != 0, stepc);
-        } while (VOTE && !__any(has && r_cur == REF_NONE));
+            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+        // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
+        // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
+        // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
+        } while (VOTE && __any(has && r_cur != REF_NONE) && (dry || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
     }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
@@ -366,9 +381,12 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
         }
         if (!__any(has)) break;
         do {
-            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, R.counters_on != 0, stepc);
-            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, R.counters_on != 0, stepc);
-        } while (VOTE && !__any(has && r_cur == REF_NONE));
+            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+        // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
+        // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
+        // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
+        } while (VOTE && __any(has && r_cur != REF_NONE) && (dry || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
     }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
