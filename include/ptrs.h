@@ -160,7 +160,14 @@ typedef struct PtrsRenderParams {
     int32_t device;             /* HIP device ordinal */
     uint32_t paths_per_pass;    /* 0 = auto */
     uint32_t flags;             /* PTRS_FLAG_* */
+    int32_t sampler;            /* PTRS_SAMPLER_*: the reference builds a SobolSamplerBuilder (main.rs:103); its StratifiedSampler
+                                   (sampler/stratified.rs) is compiled but never instantiated (sampler/mod.rs:169-170) */
+    int32_t n_sampled_dimensions; /* STRATIFIED: StratifiedSamplerBuilder::new's n_sampled_dimensions; spp = dim_pixel_samples^2.
+                                   Must cover the path: >= 3 * (max_depth + 1) + 1, because a draw past it would come straight
+                                   from the tile's generator in path order (mod.rs:137-151), which a wavefront cannot reproduce:
+                                   such a render is refused (PTRS_ERR_UNSUPPORTED) */
 } PtrsRenderParams;
+enum { PTRS_SAMPLER_SOBOL = 0, PTRS_SAMPLER_STRATIFIED = 1 };
 
 enum {
     PTRS_FLAG_COUNTERS = 1u, /* fill nodes_visited / tris_tested (slower: device atomics) */

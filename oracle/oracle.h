@@ -28,6 +28,8 @@ int orc_solve_2x2(const float *a, const float *b, float *x);
 float orc_next_float_up(float v);
 float orc_next_float_down(float v);
 float orc_detmath(int fn, float x, float y);
+int orc_stratified_tile(uint64_t seed, int32_t tile_w, int32_t tile_h, int32_t dim_pixel_samples, int32_t n_dims, float *out);
+void orc_pcg64mcg(uint64_t state_lo, uint64_t state_hi, uint32_t n, uint64_t *out);
 int orc_bsdf_eval(const PtrsMaterial *mat, const float *tex_values, uint32_t n, const float *wo,
                   const float *u, float *out);
 #ifdef __cplusplus

@@ -47,8 +47,9 @@ def _check(rc):
         raise RuntimeError("oracle error %d: %s" % (rc, lib().orc_last_error().decode()))
 
 
-def make_params(width, height, spp, max_depth, row_begin=0, row_end=0, flags=0, paths_per_pass=0):
+def make_params(width, height, spp, max_depth, row_begin=0, row_end=0, flags=0, paths_per_pass=0, sampler=0, n_sampled_dimensions=0):
     p = abi.PtrsRenderParams()
+    p.sampler, p.n_sampled_dimensions = sampler, n_sampled_dimensions
     p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
     p.rr_threshold, p.rr_start_depth, p.rr_enable = 1.0, 3, 1  # integrator.rs:240-242
     p.row_begin, p.row_end = row_begin, (row_end if row_end else height)
@@ -94,7 +95,7 @@ class OracleScene:
         W, H = params.width, params.height
         if film is None:
             film = np.zeros((H, W), dtype=abi.FILM_DTYPE)
-        spp = round_up_pow2(params.spp)
+        spp = params.spp if params.sampler == abi.SAMPLER_STRATIFIED else round_up_pow2(params.spp)
         samples = np.zeros(((H + 4), (W + 4), spp, 3), dtype=np.float32) if want_samples else None
         stats = abi.PtrsStats()
         cam = camera.to_abi()
@@ -114,6 +115,25 @@ class OracleScene:
         stats = abi.PtrsStats()
         _check(lib().orc_trace_rays(self._h, rays.shape[0], C.c_void_p(rays.ctypes.data), int(any_hit), int(brute_force), C.c_void_p(hits.ctypes.data), C.byref(stats)))
         return hits, stats
+
+
+def stratified_tile(seed, tile_w, tile_h, dim_pixel_samples, n_dims):
+    """The StratifiedSampler's tables for a tile seeded `seed`: (tile_w*tile_h pixels in x-major order, [n_dims*spp 1-D | n_dims*spp*2 2-D])."""
+    spp = dim_pixel_samples * dim_pixel_samples
+    out = np.zeros((tile_w * tile_h, n_dims * spp * 3), dtype=np.float32)
+    L = lib()
+    L.orc_stratified_tile.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    _check(L.orc_stratified_tile(int(seed), tile_w, tile_h, dim_pixel_samples, n_dims, C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def pcg64mcg(state, n):
+    out = np.zeros(n, dtype=np.uint64)
+    L = lib()
+    L.orc_pcg64mcg.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.orc_pcg64mcg.restype = None
+    L.orc_pcg64mcg(int(state) & 0xFFFFFFFFFFFFFFFF, int(state) >> 64, n, C.c_void_p(out.ctypes.data))
+    return out
 
 
 def sobol_samples(params, px, py, sample_nums, dims):

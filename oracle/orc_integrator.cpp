@@ -11,6 +11,7 @@
 #include "oracle.h"
 #include "orc_bsdf.h"
 #include "orc_sampler.h"
+#include "orc_stratified.h"
 
 namespace orc {
 
@@ -160,7 +161,8 @@ struct Integrator {
     }
 
     // uniform_sample_one_light, integrator.rs:192-217
-    Spectrum uniform_sample_one_light(const SurfaceInteraction &it, const BSDF &bsdf, SobolSampler &sampler, Counters &cnt) const {
+    template <class SAMPLER>
+    Spectrum uniform_sample_one_light(const SurfaceInteraction &it, const BSDF &bsdf, SAMPLER &sampler, Counters &cnt) const {
         size_t num_lights = scene->lights.size();
         if (num_lights == 0) return Spectrum(0.0f);
         Vec2 u_light = sampler.get_2d();
@@ -171,7 +173,8 @@ struct Integrator {
     }
 
     // li, integrator.rs:392-503
-    Spectrum li(const RayDifferential &ray_in, SobolSampler &sampler, Counters &cnt) const {
+    template <class SAMPLER>
+    Spectrum li(const RayDifferential &ray_in, SAMPLER &sampler, Counters &cnt) const {
         Spectrum l(0.0f), beta(1.0f);
         RayDifferential ray = ray_in;
         bool specular_bounce = false;
@@ -293,23 +296,29 @@ int orc_render(OrcScene *s, const PtrsCamera *cam, const PtrsRenderParams *p, Pt
     int ext_x = sb.max_x - sb.min_x, ext_y = sb.max_y - sb.min_y;
     int ntx = (ext_x + TILE - 1) / TILE, nty = (ext_y + TILE - 1) / TILE;
     SobolSampler proto; proto.configure(&g_tables, (size_t)p->spp, sb);
-    const size_t spp = proto.samples_per_pixel;
+    const bool strat = p->sampler == PTRS_SAMPLER_STRATIFIED;
+    size_t strat_dim = 1;
+    if (strat) { // StratifiedSamplerBuilder::new(log, dim_pixel_samples, n_sampled_dimensions): spp = dim^2
+        while ((strat_dim + 1) * (strat_dim + 1) <= (size_t)std::max(p->spp, 1)) ++strat_dim;
+        if (strat_dim * strat_dim != (size_t)p->spp || p->n_sampled_dimensions <= 0) { g_err = "stratified sampler: spp must be a square, n_sampled_dimensions > 0"; return PTRS_ERR_INVALID; }
+    }
+    const size_t spp = strat ? strat_dim * strat_dim : proto.samples_per_pixel;
     Integrator I = make_integrator(sc, *p);
     // band restriction (multi-GPU rehearsal): only sample rows that can touch output rows [row_begin,row_end)
     int row_b = p->row_begin, row_e = p->row_end;
     if (row_e <= row_b) { row_b = 0; row_e = p->height; }
     std::mutex merge_mu; Counters total; uint64_t n_samples = 0;
     std::atomic<int> next{0};
-    auto work = [&](int tile_id, Counters &cnt, uint64_t &ns) {
+    std::atomic<bool> strat_overrun{false};
+    auto run_tile = [&](auto &sampler, int tile_id, Counters &cnt, uint64_t &ns) {
         int tx = tile_id / nty, ty = tile_id % nty; // (x, y) with x outer
-        SobolSampler sampler = proto;
         Bounds2i tb; tb.min_x = sb.min_x + tx * TILE; tb.max_x = std::min(tb.min_x + TILE, sb.max_x);
         tb.min_y = sb.min_y + ty * TILE; tb.max_y = std::min(tb.min_y + TILE, sb.max_y);
         FilmTile tile(film, tb);
         for (int x = tb.min_x; x < tb.max_x; x++)
             for (int y = tb.min_y; y < tb.max_y; y++) {
+                sampler.start_pixel(x, y); // (also for pixels outside the band: the stratified sampler's generator runs through the whole tile)
                 if (y < row_b - 2 || y >= row_e + 2) continue; // sample rows outside the band's halo
-                sampler.start_pixel(x, y);
                 do {
                     Vec2 p_film = sampler.get_camera_sample(x, y);
                     RayDifferential ray = generate_ray_differential(*cam, p_film);
@@ -333,6 +342,19 @@ int orc_render(OrcScene *s, const PtrsCamera *cam, const PtrsRenderParams *p, Pt
                 m.rgb[0] += q[0]; m.rgb[1] += q[1]; m.rgb[2] += q[2]; m.weight += q[3];
             }
     };
+    auto work = [&](int tile_id, Counters &cnt, uint64_t &ns) {
+        if (strat) {
+            // integrator.rs:553-554: every tile gets the builder's sampler re-seeded with its index (x-major tile numbering:
+            // tile.y * num_tiles.x + tile.x)
+            const int tx = tile_id / nty, ty = tile_id % nty;
+            StratifiedSampler sampler; sampler.configure(strat_dim, (size_t)p->n_sampled_dimensions, (uint64_t)(ty * ntx + tx));
+            run_tile(sampler, tile_id, cnt, ns);
+            if (sampler.drew_from_rng) strat_overrun = true;
+        } else {
+            SobolSampler sampler = proto;
+            run_tile(sampler, tile_id, cnt, ns);
+        }
+    };
     int n_tiles = ntx * nty;
     if (n_threads <= 1) {
         Counters cnt; uint64_t ns = 0;
@@ -355,8 +377,29 @@ int orc_render(OrcScene *s, const PtrsCamera *cam, const PtrsRenderParams *p, Pt
         stats->nodes_visited = total.nodes_visited; stats->tris_tested = total.tris_tested;
         stats->bvh_nodes = sc.nodes.size(); stats->bvh_max_depth = sc.bvh_max_depth;
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (strat_overrun) stats->error_flags |= PTRS_ERRFLAG_SOBOL_DIM; // a path drew past n_sampled_dimensions (straight from the generator)
     }
     return PTRS_OK;
+}
+
+// StratifiedSampler's per-pixel tables for one tile (stratified.rs:87-148): the tile's pixels in the reference's order
+// (x outer, y inner), for each pixel n_dims x spp 1-D samples followed by n_dims x spp 2-D samples.  Also the raw generator:
+// out_u64[n] = the first n outputs of Pcg64Mcg::from_state(state_lo | state_hi << 64) when n_raw > 0.
+int orc_stratified_tile(uint64_t seed, int32_t tile_w, int32_t tile_h, int32_t dim_pixel_samples, int32_t n_dims, float *out /* w*h*n_dims*spp*3 */) {
+    StratifiedSampler sp; sp.configure((size_t)dim_pixel_samples, (size_t)n_dims, seed);
+    const size_t spp = sp.samples_per_pixel;
+    size_t o = 0;
+    for (int x = 0; x < tile_w; ++x)
+        for (int y = 0; y < tile_h; ++y) {
+            sp.start_pixel(x, y);
+            for (int d = 0; d < n_dims; ++d) for (size_t k = 0; k < spp; ++k) out[o++] = sp.samples_1d[(size_t)d][k];
+            for (int d = 0; d < n_dims; ++d) for (size_t k = 0; k < spp; ++k) { out[o++] = sp.samples_2d[(size_t)d][k].x; out[o++] = sp.samples_2d[(size_t)d][k].y; }
+        }
+    return PTRS_OK;
+}
+void orc_pcg64mcg(uint64_t state_lo, uint64_t state_hi, uint32_t n, uint64_t *out) {
+    Pcg64Mcg r = Pcg64Mcg::from_state((unsigned __int128)state_lo | ((unsigned __int128)state_hi << 64));
+    for (uint32_t i = 0; i < n; ++i) out[i] = r.next_u64();
 }
 
 // render_single_pixel, integrator.rs:505-534

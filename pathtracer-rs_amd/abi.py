@@ -13,6 +13,7 @@ WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
 MAT_MATTE, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_DISNEY, MAT_SUBSTRATE, MAT_NORMAL = range(7)
 LIGHT_POINT, LIGHT_DIRECTIONAL, LIGHT_AREA, LIGHT_INFINITE = range(4)
 FLAG_COUNTERS, FLAG_TIMING = 1, 2
+SAMPLER_SOBOL, SAMPLER_STRATIFIED = 0, 1
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -63,7 +64,8 @@ class PtrsCamera(C.Structure):
 class PtrsRenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("rr_threshold", C.c_float), ("rr_start_depth", C.c_int32), ("rr_enable", C.c_int32), ("row_begin", C.c_int32),
-                ("row_end", C.c_int32), ("device", C.c_int32), ("paths_per_pass", C.c_uint32), ("flags", C.c_uint32)]
+                ("row_end", C.c_int32), ("device", C.c_int32), ("paths_per_pass", C.c_uint32), ("flags", C.c_uint32), ("sampler", C.c_int32),
+                ("n_sampled_dimensions", C.c_int32)]
 
 
 class PtrsStats(C.Structure):

@@ -16,6 +16,7 @@
 #include "pt_bvh.h"
 #include "pt_light.h"
 #include "pt_sobol.h"
+#include "pt_stratified.h"
 
 namespace pt {
 
@@ -52,19 +53,29 @@ PT_HD PathCoord path_coord(const DParams &R, const DSampler &S, uint32_t pid) {
     return c;
 }
 
+PT_HD uint32_t strat_pack(uint32_t d1, uint32_t d2) { return (d1 & 63u) | ((d2 & 63u) << 6); } // the stratified sampler's 1-D / 2-D dimension counters in the state word's dimension field
+
 PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, const DPaths &P, uint32_t pid) {
     PathCoord c = path_coord(R, S, pid);
-    SamplerState ss;
-    ss.index = sobol_index(S, (uint64_t)c.s, (uint32_t)c.sx, (uint32_t)c.sy);
-    ss.dim = 0; ss.scramble = pixel_scramble(c.px, c.py); ss.px = c.px; ss.py = c.py;
-    f2 u = get_2d(S, ss);
+    f2 u; u4 st;
+    if (S.kind == PTRS_SAMPLER_STRATIFIED) { // get_camera_sample = the first 2-D dimension of the pixel's table (mod.rs:156-160)
+        const uint32_t pixel = (uint32_t)c.sy * (uint32_t)R.NX + (uint32_t)c.sx;
+        const float *t = S.strat2 + (((size_t)pixel * S.strat_dims + 0u) * S.spp + c.s) * 2u;
+        u = mk2(t[0], t[1]);
+        st.x = pixel; st.y = c.s; st.z = strat_pack(0u, 1u) | ST_HAS_DIFF; st.w = 0;
+    } else {
+        SamplerState ss;
+        ss.index = sobol_index(S, (uint64_t)c.s, (uint32_t)c.sx, (uint32_t)c.sy);
+        ss.dim = 0; ss.scramble = pixel_scramble(c.px, c.py); ss.px = c.px; ss.py = c.py;
+        u = get_2d(S, ss);
+        st.x = (uint32_t)ss.index; st.y = (uint32_t)(ss.index >> 32); st.z = ss.dim | ST_HAS_DIFF; st.w = ss.scramble; // the pixel's scramble travels with the path
+    }
     f2 pf = mk2((float)c.px + u.x, (float)c.py + u.y);
     CamRay r = camera_ray(C, pf, R.inv_sqrt_spp);
     P.ray_o[pid] = mkv4(r.o, PT_INF);
     P.ray_d[pid] = mkv4(r.d, 0.0f);
     P.beta[pid] = mkv4(splat3(1.0f), 1.0f);
     P.L[pid] = mkv4(splat3(0.0f), 0.0f);
-    u4 st; st.x = (uint32_t)ss.index; st.y = (uint32_t)(ss.index >> 32); st.z = ss.dim | ST_HAS_DIFF; st.w = ss.scramble; // the pixel's scramble travels with the path
     P.st[pid] = st;
     P.pfilm[pid] = mkv4(mk3(pf.x, pf.y, 0.0f), 0.0f);
 }
@@ -128,6 +139,48 @@ PT_HD uint32_t hit_flags(uint32_t x) { return x == 0xffffffffu ? 0u : ((((x >> 2
 #define PT_STAMP(k, dep)
 #endif
 
+// The draws of one shading vertex, for either sampler.  `field` is the dimension field of the path's state word: the Sobol'
+// dimension counter, or the stratified sampler's two counters (1-D in bits 0-5, 2-D in bits 6-11; mod.rs:100-101).
+struct VertexDraws { float u_nee[5], u_tail[3]; uint32_t after_cont, after_rr; bool err_cont, err_rr; };
+template <class CTX>
+PT_HD void draw_vertex(const CTX &X, const DSampler &S, const u4 &stv, bool nee, VertexDraws &D) {
+    const uint32_t field = stv.z & ST_DIM_MASK;
+    for (int k = 0; k < 5; ++k) D.u_nee[k] = 0.0f;
+    if (S.kind == PTRS_SAMPLER_STRATIFIED) {
+        // get_2d / get_1d read samples_2d[current_2d_dimension][sample] / samples_1d[...] and advance their counter (mod.rs:129-154);
+        // past n_sampled_dimensions they would draw from the generator: flagged, the render is refused
+        uint32_t d1 = field & 63u, d2 = (field >> 6) & 63u;
+        const uint32_t nd = S.strat_dims, pixel = stv.x, sidx = stv.y;
+        auto t1 = [&](uint32_t d) { return S.strat1[((size_t)pixel * nd + (d < nd ? d : nd - 1u)) * S.spp + sidx]; };
+        auto t2 = [&](uint32_t d, int c) { return S.strat2[(((size_t)pixel * nd + (d < nd ? d : nd - 1u)) * S.spp + sidx) * 2u + (uint32_t)c]; };
+        bool err = false;
+        if (nee) {
+            D.u_nee[0] = t2(d2, 0); D.u_nee[1] = t2(d2, 1); D.u_nee[2] = t2(d2 + 1u, 0); D.u_nee[3] = t2(d2 + 1u, 1); D.u_nee[4] = t1(d1);
+            err = d2 + 1u >= nd || d1 >= nd;
+            d2 += 2u; d1 += 1u;
+        }
+        D.u_tail[0] = t2(d2, 0); D.u_tail[1] = t2(d2, 1);
+        err = err || d2 >= nd;
+        d2 += 1u;
+        D.u_tail[2] = t1(d1);
+        D.after_cont = strat_pack(d1, d2); D.err_cont = err;
+        D.after_rr = strat_pack(d1 + 1u, d2); D.err_rr = err || d1 >= nd;
+        return;
+    }
+    const uint64_t index = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
+    const VertexDims V = vertex_dims(field, nee);
+    const uint32_t dt[3] = {V.cont[0], V.cont[1], V.rr};
+    if (nee) {
+        const uint32_t dn[8] = {V.nee[0], V.nee[1], V.nee[2], V.nee[3], V.nee[4], dt[0], dt[1], dt[2]};
+        float u8[8];
+        X.template sobol<8>(S, index, dn, stv.w, u8);
+        for (int k = 0; k < 5; ++k) D.u_nee[k] = u8[k];
+        D.u_tail[0] = u8[5]; D.u_tail[1] = u8[6]; D.u_tail[2] = u8[7];
+    } else X.template sobol<3>(S, index, dt, stv.w, D.u_tail);
+    D.after_cont = V.after_cont; D.err_cont = V.after_cont > 1024u; // a dimension >= 1024 was drawn: the reference panics (sobol.rs:177-183)
+    D.after_rr = V.after_cont + 1u; D.err_rr = V.after_cont + 1u > 1024u;
+}
+
 // Where shade_item finds its read-only tables.  This one reads everything from global memory (host twin, and the base of
 // the gfx950 context in ptrs_hip.hip, which serves the light records, small scenes' triangle records and the Sobol' tables
 // of the current round out of LDS: the shade kernels are bound by the number of vector-memory instructions in flight, not
@@ -170,18 +223,9 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     constexpr bool NEE_KIND = MAT != PTRS_MAT_MIRROR && MAT != PTRS_MAT_GLASS;
     const bool nee_guess = NEE_KIND && sc.n_lights > 0;
     const TriRegs T = X.tri(sc, prim, (FEAT & FEAT_IMAGE) != 0);
-    VertexDims V = vertex_dims(dim0, nee_guess);
-    float u_nee[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, u_tail[3];
-    {
-        const uint32_t dt[3] = {V.cont[0], V.cont[1], V.rr};
-        if (nee_guess) {
-            const uint32_t dn[8] = {V.nee[0], V.nee[1], V.nee[2], V.nee[3], V.nee[4], dt[0], dt[1], dt[2]};
-            float u8[8];
-            X.template sobol<8>(S, index, dn, scramble, u8);
-            for (int k = 0; k < 5; ++k) u_nee[k] = u8[k];
-            u_tail[0] = u8[5]; u_tail[1] = u8[6]; u_tail[2] = u8[7];
-        } else X.template sobol<3>(S, index, dt, scramble, u_tail);
-    }
+    VertexDraws D;
+    draw_vertex(X, S, stv, nee_guess, D);
+    float (&u_nee)[5] = D.u_nee; float (&u_tail)[3] = D.u_tail;
     PT_STAMP(1, f2u(T.ng.x) + f2u(T.p0.x) + f2u(T.n0.x) + f2u(T.uv0.x) + f2u(u_tail[2]) + f2u(u_nee[4]) + T.flags)
     // ---- round trip 3: the light record (its index is the fifth draw) and the material record ---------------------
     uint32_t li = 0;
@@ -217,11 +261,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     // ---- direct lighting: uniform_sample_one_light + estimate_direct up to the scene queries ----
     const uint32_t NS = BSDF_ALL & ~BSDF_SPECULAR;
     const bool do_nee = bsdf_num(bsdf, NS) > 0 && sc.n_lights > 0;
-    if (do_nee != nee_guess) { // only a lobeless Substrate gets here (do_nee false, nee_guess true): its draws start at dim0
-        V = vertex_dims(dim0, false);
-        const uint32_t dt[3] = {V.cont[0], V.cont[1], V.rr};
-        X.template sobol<3>(S, index, dt, scramble, u_tail);
-    }
+    if (do_nee != nee_guess) draw_vertex(X, S, stv, false, D); // only a lobeless Substrate gets here (do_nee false, nee_guess true): its draws start at the vertex's first dimension
     if (do_nee) {
         DLight Lt; // a register copy of the light's record (LDS-resident for scenes with few lights): the fields its kind reads are fetched together
         X.light(sc, li, Lt);
@@ -277,12 +317,12 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     }
 
     // ---- continuation: integrator.rs:449-499 ---------------------------------------------------
-    uint32_t dim = V.after_cont;
+    uint32_t dim = D.after_cont;
     f3 wi = splat3(0.0f);
     float pdf = 0.0f; uint32_t flags = 0;
     f3 f = bsdf_sample_f(bsdf, wo, wi, mk2(u_tail[0], u_tail[1]), pdf, BSDF_ALL, flags);
     bool alive = true;
-    if (dim > 1024u) { out.err_dim = true; alive = false; } // a dimension >= 1024 was drawn: the reference panics here
+    if (D.err_cont) { out.err_dim = true; alive = false; } // a draw outside the sampler's dimensions: the reference panics (Sobol') / leaves the tables (stratified)
     if (is_black(f) || pdf == 0.0f) alive = false;
     if (alive) {
         beta = beta * (f * fabs_(dot(wi, s.ns)) / pdf);
@@ -296,8 +336,8 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             float mx = max_comp(beta * eta_scale);
             if (mx < R.rr_threshold && bounces > R.rr_start_depth) {
                 float q = max_(0.05f, 1.0f - mx);
-                dim += 1; // get_1d
-                if (dim > 1024u) { out.err_dim = true; alive = false; }
+                dim = D.after_rr; // get_1d
+                if (D.err_rr) { out.err_dim = true; alive = false; }
                 else if (u_tail[2] < q) alive = false;
                 else beta = beta / (1.0f - q);
             }

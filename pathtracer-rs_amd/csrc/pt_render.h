@@ -147,7 +147,18 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     auto t_begin = clock::now();
     if (prm.width <= 0 || prm.height <= 0 || prm.spp <= 0 || prm.max_depth < 0) { err = "bad render parameters"; return PTRS_ERR_INVALID; }
     if (bvh_depth > 64) { err = "BVH deeper than the 64-entry traversal stack (accelerator.rs:370)"; return PTRS_ERR_UNSUPPORTED; }
-    const SampleGrid g = make_sample_grid(prm.width, prm.height, prm.spp);
+    SampleGrid g = make_sample_grid(prm.width, prm.height, prm.spp);
+    uint32_t strat_dim = 0;
+    if (prm.sampler == PTRS_SAMPLER_STRATIFIED) { // StratifiedSamplerBuilder::new(log, dim_pixel_samples, n_sampled_dimensions) (stratified.rs:22-36)
+        strat_dim = 1; while ((strat_dim + 1u) * (strat_dim + 1u) <= (uint32_t)prm.spp) ++strat_dim;
+        if (strat_dim * strat_dim != (uint32_t)prm.spp) { err = "stratified sampler: spp must be dim_pixel_samples squared"; return PTRS_ERR_INVALID; }
+        if (prm.n_sampled_dimensions < 3 * (prm.max_depth + 1) + 1 || prm.n_sampled_dimensions > 63) {
+            err = "stratified sampler: n_sampled_dimensions must cover the path (3 * (max_depth + 1) + 1 .. 63): draws past it come from the tile's generator in path order (sampler/mod.rs:137-151), which a wavefront cannot reproduce";
+            return PTRS_ERR_UNSUPPORTED;
+        }
+        if (single_pixel) { err = "render_single_pixel with the stratified sampler is not supported (its tables depend on the tile's earlier pixels)"; return PTRS_ERR_UNSUPPORTED; }
+        g.spp = strat_dim * strat_dim;
+    } else if (prm.sampler != PTRS_SAMPLER_SOBOL) { err = "unknown sampler"; return PTRS_ERR_INVALID; }
     if (g.log2_res < 1 || g.log2_res > 25 || 2u * g.log2_res + (31u - (uint32_t)__builtin_clz(g.spp)) > 62u) { err = "resolution / spp outside the Sobol index range"; return PTRS_ERR_UNSUPPORTED; }
     int32_t rb = prm.row_begin, re = prm.row_end;
     if (re <= rb) { rb = 0; re = prm.height; }
@@ -164,6 +175,11 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     DSampler S;
     S.matrices = be.sobol_matrices(); S.bytetab = be.sobol_bytetab(); S.nibtab = be.sobol_nibtab(); S.vdc = be.sobol_vdc(g.log2_res - 1); S.vdc_inv = be.sobol_vdc_inv(g.log2_res - 1);
     S.log2_res = g.log2_res; S.resolution = g.resolution; S.min_x = g.min_x; S.min_y = g.min_y; S.spp = g.spp;
+    S.kind = (uint32_t)prm.sampler; S.strat_dims = (uint32_t)prm.n_sampled_dimensions; S.strat1 = nullptr; S.strat2 = nullptr;
+    if (strat_dim) { // every tile's generator runs through the whole tile, whichever rows this call renders
+        int rc_t = be.strat_tables(g.NX, g.NY, strat_dim, S.strat_dims, &S.strat1, &S.strat2, err);
+        if (rc_t != PTRS_OK) return rc_t;
+    }
     DCamera C;
     std::memcpy(C.rot, cam.rot, 16); std::memcpy(C.trans, cam.trans, 12);
     C.m00 = cam.m00; C.m11 = cam.m11; C.m22 = cam.m22; C.m23 = cam.m23;
@@ -274,7 +290,11 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     st.bvh_nodes = sc.n_nodes; st.bvh_max_depth = bvh_depth;
     st.ms_total = std::chrono::duration<double, std::milli>(clock::now() - t_begin).count();
     if (stats) *stats = st;
-    if (st.error_flags & PTRS_ERRFLAG_SOBOL_DIM) { err = "sobol sampler can only sample up to 1024 dimensions (sobol.rs:177-183): max_depth is too large for this scene"; return PTRS_ERR_UNSUPPORTED; }
+    if (st.error_flags & PTRS_ERRFLAG_SOBOL_DIM) {
+        err = strat_dim ? "stratified sampler: a path drew past n_sampled_dimensions (null-BSDF skips lengthen paths beyond max_depth, Q7); the reference would continue from the tile's generator in path order, which a wavefront cannot reproduce"
+                        : "sobol sampler can only sample up to 1024 dimensions (sobol.rs:177-183): max_depth is too large for this scene";
+        return PTRS_ERR_UNSUPPORTED;
+    }
     if (st.error_flags & PTRS_ERRFLAG_NULL_SKIPS) { err = "paths still alive after max_depth + 65 rounds of null-BSDF skips (integrator.rs:434-439)"; return PTRS_ERR_UNSUPPORTED; }
     return PTRS_OK;
 }

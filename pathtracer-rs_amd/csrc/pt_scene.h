@@ -142,7 +142,11 @@ struct DSampler { // SobolSamplerBuilder::new (sobol.rs:35-60) + table rows
     uint32_t log2_res;
     int32_t resolution;
     int32_t min_x, min_y; // sample bounds p_min
-    uint32_t spp;         // power of two
+    uint32_t spp;         // Sobol': power of two; stratified: dim_pixel_samples^2
+    // PTRS_SAMPLER_STRATIFIED (pt_stratified.h): per-pixel tables made by k_strat_tables before the passes
+    uint32_t kind, strat_dims;  // kind = PTRS_SAMPLER_*; n_sampled_dimensions
+    const float *strat1;        // [NX*NY][strat_dims][spp]
+    const float *strat2;        // [NX*NY][strat_dims][spp][2]
 };
 
 struct DCamera { // = PtrsCamera

@@ -671,6 +671,16 @@ __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P,
     if (live) film[(size_t)y * (size_t)R.W + (size_t)x] = acc;
 }
 
+// The stratified sampler's tables: one thread per 16x16 tile of the sample bounds, seeded with the tile's index like the
+// reference's tile loop (integrator.rs:551-563: seed = tile.y * num_tiles.x + tile.x), sequential inside the tile.
+__global__ __launch_bounds__(64) void k_strat_tables(int32_t NX, int32_t NY, uint32_t dim_ps, uint32_t n_dims, float *tab1, float *tab2) {
+    const int32_t ntx = (NX + 15) / 16, nty = (NY + 15) / 16;
+    const int32_t t = (int32_t)(blockIdx.x * 64u + threadIdx.x);
+    if (t >= ntx * nty) return;
+    const int32_t tx = t % ntx, ty = t / ntx;
+    stratified_tile_tables((uint64_t)(ty * ntx + tx), tx * 16, min(tx * 16 + 16, NX), ty * 16, min(ty * 16 + 16, NY), NX, dim_ps, n_dims, tab1, tab2);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_export_samples(DParams R, DSampler S, DPaths P, float *out) {
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < R.n_paths; pid += stride) {
@@ -774,13 +784,13 @@ struct PtrsScene {
     // render workspace, grown on demand and reused across calls
     DevBuf ws[MAX_LANES][32];   // per pipeline lane
     DevBuf counts[MAX_LANES], totals[MAX_LANES];
-    DevBuf stats, table, film_tmp, samples_tmp;
+    DevBuf stats, table, film_tmp, samples_tmp, strat1, strat2;
     hipStream_t lane_stream[MAX_LANES] = {}; // lane 0 runs on the caller's stream, the others on these
     hipEvent_t lane_ev[MAX_LANES] = {};      // film-done per lane
     std::vector<hipEvent_t> ev_pool;
     int n_cu = 256;
     ~PtrsScene() {
-        for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &stats, &table, &film_tmp, &samples_tmp}) b->release();
+        for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &stats, &table, &film_tmp, &samples_tmp, &strat1, &strat2}) b->release();
         for (auto &b : counts) b.release();
         for (auto &b : totals) b.release();
         for (auto &l : ws) for (auto &b : l) b.release();
@@ -836,6 +846,18 @@ struct HipBackend {
     const uint32_t *sobol_matrices() { return (const uint32_t *)sob->matrices.p; }
     const uint32_t *sobol_bytetab() { return (const uint32_t *)sob->bytetab.p; }
     const uint32_t *sobol_nibtab() { return (const uint32_t *)sob->nibtab.p; }
+    int strat_tables(int32_t NX, int32_t NY, uint32_t dim_ps, uint32_t n_dims, const float **t1, const float **t2, std::string &err) {
+        const size_t n = (size_t)NX * (size_t)NY * n_dims * dim_ps * dim_ps;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && n * 12 > (fr + ps->strat1.bytes + ps->strat2.bytes) / 2) { err = "stratified sampler: the per-pixel tables (" + std::to_string(n * 12 >> 20) + " MiB) do not fit"; return PTRS_ERR_UNSUPPORTED; }
+        int rc;
+        if ((rc = ps->strat1.ensure(n * 4)) != PTRS_OK || (rc = ps->strat2.ensure(n * 8)) != PTRS_OK) { err = g_err; return rc; }
+        const int32_t tiles = ((NX + 15) / 16) * ((NY + 15) / 16);
+        hipLaunchKernelGGL(k_strat_tables, dim3((uint32_t)(tiles + 63) / 64), dim3(64), 0, stream, NX, NY, dim_ps, n_dims, (float *)ps->strat1.p, (float *)ps->strat2.p);
+        if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) { err = "stratified table kernel failed"; return PTRS_ERR_DEVICE; }
+        *t1 = (const float *)ps->strat1.p; *t2 = (const float *)ps->strat2.p;
+        return PTRS_OK;
+    }
     const uint64_t *sobol_vdc(uint32_t row) { return (const uint64_t *)sob->vdc.p + (size_t)row * sob->stride; }
     const uint64_t *sobol_vdc_inv(uint32_t row) { return (const uint64_t *)sob->vdc_inv.p + (size_t)row * sob->stride; }
 
@@ -1168,7 +1190,8 @@ static int render_samples_impl(PtrsScene *scene, const PtrsCamera *camera, const
     float *sdev = nullptr; size_t sbytes = 0;
     if (sample_rgb) {
         const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
-        sbytes = (size_t)g.NX * (size_t)g.NY * (size_t)g.spp * 3 * sizeof(float);
+        const size_t spp = params->sampler == PTRS_SAMPLER_STRATIFIED ? (size_t)std::max(params->spp, 1) : (size_t)g.spp; // the stratified sampler takes spp = dim^2 as is
+        sbytes = (size_t)g.NX * (size_t)g.NY * spp * 3 * sizeof(float);
         if ((rc = scene->samples_tmp.ensure(sbytes)) != PTRS_OK) return rc;
         HIPCHK(hipMemset(scene->samples_tmp.p, 0, sbytes));
         sdev = (float *)scene->samples_tmp.p;

@@ -108,6 +108,20 @@ class SamplerBuilder:
         return self
 
 
+class StratifiedSamplerBuilder:
+    """StratifiedSamplerBuilder::new(log, dim_pixel_samples, n_sampled_dimensions) (sampler/stratified.rs:22-36): spp =
+    dim_pixel_samples^2, jittered.  The reference compiles this sampler but never builds one (sampler/mod.rs:169-170); here
+    it selects PtrsRenderParams.sampler = PTRS_SAMPLER_STRATIFIED.  with_seed is applied per tile by render (integrator.rs:553)."""
+
+    def __init__(self, dim_pixel_samples, n_sampled_dimensions):
+        self.dim_pixel_samples = int(dim_pixel_samples)
+        self.n_sampled_dimensions = int(n_sampled_dimensions)
+        self.samples_per_pixel = self.dim_pixel_samples * self.dim_pixel_samples
+
+    def with_seed(self, _seed):
+        return self
+
+
 class _DeviceScene:
     def __init__(self, render_scene, device=0, bvh=None):
         self.handle = C.c_void_p()
@@ -167,6 +181,8 @@ class PathIntegrator:
         p.rr_threshold, p.rr_start_depth, p.rr_enable = self.rr_threshold, self.rr_start_depth, int(self.rr_enable)
         p.row_begin, p.row_end = row_begin, (row_end if row_end else camera.film.height)
         p.device, p.paths_per_pass, p.flags = self.device, self.paths_per_pass, flags
+        if isinstance(self.sampler_builder, StratifiedSamplerBuilder):
+            p.sampler, p.n_sampled_dimensions = abi.SAMPLER_STRATIFIED, self.sampler_builder.n_sampled_dimensions
         return p
 
     def render(self, camera, scene, row_begin=0, row_end=0, flags=0, want_samples=False):
@@ -178,7 +194,7 @@ class PathIntegrator:
         film = camera.film.pixels
         samples = None
         if want_samples:
-            samples = np.zeros((p.height + 4, p.width + 4, round_up_pow2(p.spp), 3), dtype=np.float32)
+            samples = np.zeros((p.height + 4, p.width + 4, p.spp if p.sampler == abi.SAMPLER_STRATIFIED else round_up_pow2(p.spp), 3), dtype=np.float32)
         _check(load_library().ptrs_render_samples(ds.handle, C.byref(cam), C.byref(p), C.c_void_p(film.ctypes.data),
                                                   C.c_void_p(samples.ctypes.data) if want_samples else None, C.byref(stats)))
         self.last_stats = stats

@@ -49,6 +49,17 @@ struct HostBackend {
     const uint32_t *sobol_matrices() { return g_tables.matrices.data(); }
     const uint32_t *sobol_bytetab() { return g_use_bytetab ? g_bytetab.data() : nullptr; }
     const uint32_t *sobol_nibtab() { return nullptr; }
+    std::vector<float> strat1, strat2;
+    int strat_tables(int32_t NX, int32_t NY, uint32_t dim_ps, uint32_t n_dims, const float **t1, const float **t2, std::string &) {
+        const size_t n = (size_t)NX * (size_t)NY * n_dims * dim_ps * dim_ps;
+        strat1.assign(n, 0.0f); strat2.assign(n * 2, 0.0f);
+        const int32_t ntx = (NX + 15) / 16, nty = (NY + 15) / 16;
+        for (int32_t ty = 0; ty < nty; ++ty)
+            for (int32_t tx = 0; tx < ntx; ++tx)
+                stratified_tile_tables((uint64_t)(ty * ntx + tx), tx * 16, std::min(tx * 16 + 16, NX), ty * 16, std::min(ty * 16 + 16, NY), NX, dim_ps, n_dims, strat1.data(), strat2.data());
+        *t1 = strat1.data(); *t2 = strat2.data();
+        return PTRS_OK;
+    }
     const uint64_t *sobol_vdc(uint32_t row) { return g_tables.vdc.data() + (size_t)row * g_tables.stride; }
     const uint64_t *sobol_vdc_inv(uint32_t row) { return g_tables.vdc_inv.data() + (size_t)row * g_tables.stride; }
 

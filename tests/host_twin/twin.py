@@ -50,7 +50,7 @@ class TwinScene:
         W, H = params.width, params.height
         if film is None:
             film = np.zeros((H, W), dtype=abi.FILM_DTYPE)
-        spp = round_up_pow2(params.spp)
+        spp = params.spp if params.sampler == abi.SAMPLER_STRATIFIED else round_up_pow2(params.spp)
         samples = np.zeros((H + 4, W + 4, spp, 3), dtype=np.float32) if want_samples else None
         stats = abi.PtrsStats()
         cam = camera.to_abi()
