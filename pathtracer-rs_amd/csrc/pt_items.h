@@ -313,6 +313,12 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             w_nee1 = mkv4(fB, spdf);
             w_nee2.x = f2u(beta.x); w_nee2.y = f2u(beta.y); w_nee2.z = f2u(beta.z);
             w_nee2.w = li | ((out.shadow ? NEE_SHADOW : 0u) | (out.mis ? NEE_MIS : 0u)) << 24;
+            if (!out.mis) { // shadow ray only (always, for delta lights): resolve_item's arithmetic with its one unknown, the occlusion, left open
+                f3 ld = splat3(0.0f);
+                ld = ld + A;
+                w_nee0 = mkv4(beta * ((float)sc.n_lights * ld), 0.0f);
+                w_nee2.w |= NEE_PRE << 24;
+            }
         }
     }
 
@@ -358,7 +364,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     X.before_stores();
     if (out.shadow) { P.sh_o[pid] = w_sh_o; P.sh_d[pid] = w_sh_d; }
     if (out.mis) { P.mis_o[pid] = w_mis_o; P.mis_d[pid] = w_mis_d; }
-    if (out.nee) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; }
+    if (out.nee) { P.nee0[pid] = w_nee0; if (out.mis) P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; }
     if (w_skip) { P.ray_o[pid] = w_ro; P.st[pid] = w_st; out.next = true; }
     else if (out.next) { P.ray_o[pid] = w_ro; P.ray_d[pid] = w_rd; P.beta[pid] = w_beta; P.st[pid] = w_st; }
     PT_STAMP(8, 0u)
@@ -372,9 +378,13 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 // closest hit (prim < 0: it escaped).
 template <int FEAT>
 PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid, bool occluded, const HitRec &mh) {
-    const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
     const u4 n2 = P.nee2[pid];
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
+    if (fl & NEE_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (nee0.xyz = beta * nLights * ld)
+        if (!occluded) { const v4 c = P.nee0[pid], Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + xyz(c), Lv.w); }
+        return;
+    }
+    const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
     f3 ld = splat3(0.0f);
     if ((fl & NEE_SHADOW) && !occluded) ld = ld + xyz(n0);
     if (fl & NEE_MIS) {

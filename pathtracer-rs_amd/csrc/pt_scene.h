@@ -177,7 +177,9 @@ struct alignas(16) u4 { uint32_t x, y, z, w; };
 // path-state bits (u4.z of `st`)
 enum : uint32_t { ST_DIM_MASK = 0xfffu, ST_SPECULAR = 1u << 12, ST_HAS_DIFF = 1u << 13, ST_BOUNCE_SHIFT = 16 };
 // nee flags (stored in nee2.w as bits)
-enum : uint32_t { NEE_SHADOW = 1u, NEE_MIS = 2u, NEE_OCCLUDED = 0x80u }; // OCCLUDED: set by the split connect stage when the shadow ray was blocked
+enum : uint32_t { NEE_SHADOW = 1u, NEE_MIS = 2u,
+                  NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in nee0.xyz: the connect stage adds it when the ray is free
+                  NEE_OCCLUDED = 0x80u }; // set by the split connect stage when the shadow ray was blocked
 
 struct DPaths {
     v4 *ray_o;  // o.xyz, (unused)

@@ -37,7 +37,7 @@ thread_local std::string g_err;
 struct Options {
     int lanes = 3;            // concurrent pipeline lanes (own path state, queues and stream each), 1..MAX_LANES
     int refill = 16;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend
-    int refill_connect = -1;  // the same for the connection kernel; -1 = by scene (quad form: 16, LDS-resident pair form: fused kernel)
+    int refill_connect = 16;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
     int grid_mult = 1;        // workgroups per pass in units of the resident capacity (8 per CU)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
@@ -350,12 +350,18 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
     uint32_t nn = 0, nt = 0, pid = 0, fl = 0; StepCount stepc;
     bool has = false, dry = n == 0, shadow_phase = false, setup = false;
+    v4 pre_c, pre_l; pre_c.x = pre_c.y = pre_c.z = pre_c.w = 0.0f; pre_l = pre_c; // NEE_PRE records: the contribution and the path's radiance, fetched with the ray
     RF_DECL
     for (;;) {
         if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
             if (shadow_phase) {
+                if (fl & NEE_PRE) { // a shadow-only record is resolved here: l += beta * nLights * ld unless the ray was blocked (integrator.rs:66-78, 444-446)
+                    if (!r_hit) { v4 o = pre_l; o.x = pre_l.x + pre_c.x; o.y = pre_l.y + pre_c.y; o.z = pre_l.z + pre_c.z; P.L[pid] = o; }
+                    has = false;
+                } else {
                 if (r_hit) reinterpret_cast<uint32_t *>(P.nee2 + pid)[3] |= NEE_OCCLUDED << 24;
                 if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
+                }
             } else {
                 u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
                 P.hit[pid] = v;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
             if (cursor >= n) dry = true;
         }
         if (setup) {
-            if (shadow_phase) { const v4 o = P.sh_o[pid], d = P.sh_d[pid]; RF_START(xyz(o), xyz(d), o.w) }
+            if (shadow_phase) { const v4 o = P.sh_o[pid], d = P.sh_d[pid]; if (fl & NEE_PRE) { pre_c = P.nee0[pid]; pre_l = P.L[pid]; } RF_START(xyz(o), xyz(d), o.w) }
             else { const v4 o = P.mis_o[pid], d = P.mis_d[pid]; RF_START(xyz(o), xyz(d), PT_INF) }
             stk.clear(); setup = false;
         }
@@ -397,9 +403,11 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues 
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
+    if (*seg_count(Q, it, Q_MIS, G, b) == 0) return; // every record of the segment was shadow-only: k_connect_rf has resolved them
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
         const uint32_t pid = queue[i];
         const uint32_t fl = P.nee2[pid].w >> 24;
+        if (fl & NEE_PRE) continue;
         HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
         if (fl & NEE_MIS) { const u4 v = P.hit[pid]; mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
         resolve_item<FEAT>(sc, P, pid, (fl & NEE_OCCLUDED) != 0, mh);
@@ -876,7 +884,7 @@ struct HipBackend {
         grid_max = ps->n_cu * 8 * ps->grid_mult;
         // measured (single lane, Mray/s): Cornell (pair form, LDS) extend-refill 5722 vs none 5560, with connect-refill 5666;
         // colonnade (quad form) none 1517, extend 1698, both 1830
-        refill_connect = opt.refill_connect >= 0 ? (uint32_t)opt.refill_connect : (sc.n_nodes4 ? 16u : 0u);
+        refill_connect = (uint32_t)(opt.refill_connect < 0 ? 16 : opt.refill_connect);
         refill = (uint32_t)opt.refill;
         vote = opt.vote >= 0 ? opt.vote != 0 : sc.n_nodes4 != 0;
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
