@@ -173,11 +173,12 @@ PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg
     uint32_t r0 = f2u(q[6].x), r1 = f2u(q[6].y), r2 = f2u(q[6].z), r3 = f2u(q[6].w);
     const uint32_t axes = f2u(q[7].x);
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-    bool h0 = (r0 != REF_NONE) & slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0); h0 = h0 & (t0 < t_max);
-    bool h1 = (r1 != REF_NONE) & slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1); h1 = h1 & (t1 < t_max);
-    bool h2 = (r2 != REF_NONE) & slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2); h2 = h2 & (t2 < t_max);
-    bool h3 = (r3 != REF_NONE) & slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3); h3 = h3 & (t3 < t_max);
-    n_nodes += (r0 != REF_NONE) + (r1 != REF_NONE) + (r2 != REF_NONE) + (r3 != REF_NONE);
+    // (an empty slot's box is (+inf, -inf): its test fails by itself)
+    bool h0 = slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0); h0 = h0 & (t0 < t_max);
+    bool h1 = slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1); h1 = h1 & (t1 < t_max);
+    bool h2 = slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2); h2 = h2 & (t2 < t_max);
+    bool h3 = slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3); h3 = h3 & (t3 < t_max);
+    n_nodes += (axes >> 12) & 7u;
     const uint32_t ax = axes & 3u, aa = (axes >> 2) & 3u, ab = (axes >> 4) & 3u;
     const bool sw = ax < 3u && neg[ax], swa = aa < 3u && neg[aa], swb = ab < 3u && neg[ab];
     if (axes & 0x100u) { t0 = t1 = t2 = t3 = -3.402823466e38f; } // chunks of one leaf: no pop-time re-test

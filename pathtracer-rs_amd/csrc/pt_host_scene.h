@@ -344,7 +344,9 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
                 b[0] = nd.pmin[0]; b[1] = nd.pmin[1]; b[2] = nd.pmin[2]; b[3] = nd.pmax0; b[4] = nd.pmax1; b[5] = nd.pmax2;
                 d.ref[s] = ref;
             }
-            static DNode4 blank() { DNode4 d; std::memset(&d, 0, sizeof(d)); for (int s = 0; s < 4; ++s) d.ref[s] = REF_NONE; return d; }
+            // an empty slot holds the box no ray can enter (min = +inf, max = -inf: its slab test ends with t_max_box = -inf > 0 false for every
+            // finite origin and any direction, infinite reciprocals included), so traversal needs no test for REF_NONE
+            static DNode4 blank() { DNode4 d; std::memset(&d, 0, sizeof(d)); for (int s = 0; s < 4; ++s) { d.ref[s] = REF_NONE; for (int k = 0; k < 3; ++k) { d.box[6 * s + k] = PT_INF; d.box[6 * s + 3 + k] = -PT_INF; } } return d; }
             // reference to a leaf range; ranges longer than REF_MAX_LEAF (only possible when many centroids coincide)
             // become quad nodes whose slots are consecutive chunks sharing the leaf's box, visited in order and
             // popped without the entry re-test (the reference tests such a leaf's box once)
@@ -384,6 +386,7 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             DNode4 d = Conv::blank(); Conv::set_slot(d, 0, H.nodes[0], root); d.axes = 3u | (3u << 2) | (3u << 4);
             H.nodes4.insert(H.nodes4.begin(), d);
         }
+        for (DNode4 &d : H.nodes4) { uint32_t c = 0; for (int sl = 0; sl < 4; ++sl) c += d.ref[sl] != REF_NONE ? 1u : 0u; d.axes = (d.axes & 0xfffu) | (c << 12); } // bits 12-14: occupied slots (the boxes-tested statistic)
         // stack bound: at most three entries are stacked per level of the quad tree
         std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 1u});
         uint32_t depth4 = 0;

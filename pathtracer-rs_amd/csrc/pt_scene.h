@@ -35,7 +35,8 @@ static_assert(sizeof(DNode2) == 64, "node2");
 // children of the node's first child A, slots 2,3 those of its second child B; when A (or B) is itself a leaf it
 // occupies slot 0 (or 2) and slot 1 (or 3) is REF_NONE.  Box s = floats [6s, 6s+6) = min xyz, max xyz.
 // axes: bits 0-1 split axis of the node, 2-3 of A, 4-5 of B (3 = never swap); bit 8: entries stacked from this node
-// are popped without the entry-distance re-test (chunks of one over-long leaf share the leaf's box).
+// are popped without the entry-distance re-test (chunks of one over-long leaf share the leaf's box); bits 12-14: number of
+// occupied slots.  An empty slot (ref REF_NONE) holds the box (+inf, -inf), which no ray enters.
 // Visiting [near group: near slot, far slot][far group: near slot, far slot] reproduces the binary traversal's
 // order (accelerator.rs:397-408) with half the dependent fetches.
 struct alignas(16) DNode4 {
