@@ -248,6 +248,16 @@ int ptrs_scene_info(PtrsScene *scene, uint64_t *n_nodes, uint64_t *max_depth, ui
 int ptrs_render(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params,
                 PtrsFilmPixel *film_inout, PtrsStats *stats);
 
+/* render with the film visible while it forms -- what the reference's preview thread gets by reading the shared film
+ * every two seconds while render() runs (headless.rs:197-214).  After every pass of the
+ * wavefront pipeline (a block of sample rows x a block of sample indices) whose film kernel has finished, the output rows
+ * it touched are copied into film_inout and `fn(user, passes_done, passes_total, row_begin, row_end)` is called on the
+ * calling thread; the rows hold the samples accumulated so far (rgb and weight sums: divide to display, film.rs:253-271).
+ * The final film is bit-identical to ptrs_render's. */
+typedef void (*PtrsProgressFn)(void *user, uint32_t passes_done, uint32_t passes_total, int32_t row_begin, int32_t row_end);
+int ptrs_render_progressive(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params,
+                            PtrsFilmPixel *film_inout, PtrsProgressFn fn, void *user, PtrsStats *stats);
+
 /* One process, several devices (the reference host is one process: main.rs:101-126).  scenes[i] is the same scene
  * created on device i (ptrs_scene_create with that ordinal); output rows [band_bounds[i], band_bounds[i+1]) are rendered
  * by scenes[i] on a host thread of its own, gathered into scenes[0]'s device with peer copies and returned in

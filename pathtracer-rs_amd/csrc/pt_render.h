@@ -137,9 +137,12 @@ inline void plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_
     }
 }
 
+struct RenderProgress { void (*fn)(void *user, uint32_t done, uint32_t total, int32_t row_begin, int32_t row_end); void *user; };
+
 template <class BE>
 int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_t bvh_depth, const PtrsCamera &cam, const PtrsRenderParams &prm,
                 v4 *film /* backend memory, W*H */, float *samples_out /* backend memory or null */, PtrsStats *stats, std::string &err,
+                const RenderProgress *progress = nullptr /* called after every pass with the rows it touched (back end copies them out first) */,
                 const int32_t *single_pixel = nullptr /* render_single_pixel (integrator.rs:505-534): raster (px, py), any pixel of the sample bounds;
                                                          traces that pixel's spp paths only, no film, samples_out = spp * 3 floats */) {
     using clock = std::chrono::steady_clock;
@@ -252,6 +255,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     };
     uint32_t pass_no = 0;
     bool null_skip_overrun = false;
+    const uint32_t n_passes_total = (uint32_t)(((band_rows + rows_per_pass - 1) / rows_per_pass) * ((g.spp + samples_per_pass - 1) / samples_per_pass));
     for (int32_t r0 = srow0; r0 < srow1; r0 += (int32_t)rows_per_pass) {
         const int32_t r1 = std::min<int32_t>(srow1, r0 + (int32_t)rows_per_pass);
         for (uint32_t s0 = 0; s0 < g.spp; s0 += (uint32_t)samples_per_pass, ++pass_no) {
@@ -280,6 +284,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
             const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);
             if (y1 > y0 && !single_pixel) be.film(film, y0, y1); // ordered after the previous pass's film kernel, whichever lane ran it
+            if (progress && progress->fn && y1 > y0 && !single_pixel) { be.publish_rows(film, y0, y1); progress->fn(progress->user, pass_no + 1u, n_passes_total, y0, y1); }
             if (samples_out) be.export_samples(samples_out);
             pending[lane].active = true; pending[lane].it = it; pending[lane].n_paths = R.n_paths;
         }

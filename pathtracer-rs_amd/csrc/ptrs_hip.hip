@@ -1032,6 +1032,13 @@ struct HipBackend {
         t0(T_FILM); hipLaunchKernelGGL(k_film, dim3((uint32_t)tiles_x * (uint32_t)tiles_y), dim3(BLOCK), 0, stream, R, S, P, (const float *)ps->table.p, film_px, y0, y1, tiles_x); t1();
         if (n_lanes > 1) { film_prev = ps->lane_ev[cur]; (void)hipEventRecord(film_prev, stream); }
     }
+    // progressive render: wait for this lane's film kernel (and, through the chain of events, every earlier pass's) and copy the rows out
+    PtrsFilmPixel *host_film = nullptr; int32_t film_w = 0;
+    void publish_rows(v4 *film_px, int32_t y0, int32_t y1) {
+        if (!host_film || hipStreamSynchronize(stream) != hipSuccess) { rc = host_film ? PTRS_ERR_DEVICE : rc; return; }
+        const size_t off = (size_t)y0 * (size_t)film_w, cnt = (size_t)(y1 - y0) * (size_t)film_w;
+        if (hipMemcpy(host_film + off, film_px + off, cnt * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost) != hipSuccess) rc = PTRS_ERR_DEVICE;
+    }
     void export_samples(float *out) { t0(T_FILM); hipLaunchKernelGGL(k_export_samples, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, P, out); t1(); }
     void end(PtrsStats &st) {
         for (uint32_t l = 0; l < n_lanes; ++l) { select(l); if (hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE; }
@@ -1058,15 +1065,16 @@ struct HipBackend {
     }
 };
 
-int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm, v4 *film_dev, float *samples_dev, hipStream_t stream, PtrsStats *stats, const int32_t *single_pixel = nullptr) {
+int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm, v4 *film_dev, float *samples_dev, hipStream_t stream, PtrsStats *stats, const int32_t *single_pixel = nullptr,
+              const RenderProgress *progress = nullptr, PtrsFilmPixel *host_film = nullptr) {
     if (!ps || !cam || !prm || (!film_dev && !single_pixel)) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     HIPCHK(hipSetDevice(ps->device));
     HipBackend be;
-    be.ps = ps; be.stream = stream; be.opt = options();
+    be.ps = ps; be.stream = stream; be.opt = options(); be.host_film = host_film; be.film_w = prm->width;
     int rc = get_sobol(ps->device, &be.sob);
     if (rc != PTRS_OK) return rc;
     std::string err;
-    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err, single_pixel);
+    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err, progress, single_pixel);
     if (rc != PTRS_OK) { if (!err.empty()) g_err = err; return rc; }
     if (be.rc != PTRS_OK) { if (g_err.empty()) g_err = "device error during render"; return be.rc; }
     return PTRS_OK;
@@ -1213,6 +1221,26 @@ static int render_samples_impl(PtrsScene *scene, const PtrsCamera *camera, const
 
 int ptrs_render(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, PtrsStats *stats) {
     return ptrs_render_samples(scene, camera, params, film_inout, nullptr, stats);
+}
+
+int ptrs_render_progressive(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, PtrsFilmPixel *film_inout, PtrsProgressFn fn, void *user, PtrsStats *stats) {
+    return guarded([&]() -> int {
+        if (!scene || !params || !film_inout) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+        HIPCHK(hipSetDevice(scene->device));
+        int32_t rb = params->row_begin, re = params->row_end;
+        if (re <= rb) { rb = 0; re = params->height; }
+        if (rb < 0 || re > params->height) { g_err = "row band outside the film"; return PTRS_ERR_INVALID; }
+        const size_t npx = (size_t)params->width * (size_t)params->height;
+        int rc = scene->film_tmp.ensure(npx * sizeof(PtrsFilmPixel));
+        if (rc != PTRS_OK) return rc;
+        const size_t off = (size_t)rb * (size_t)params->width, cnt = (size_t)(re - rb) * (size_t)params->width;
+        HIPCHK(hipMemcpy((PtrsFilmPixel *)scene->film_tmp.p + off, film_inout + off, cnt * sizeof(PtrsFilmPixel), hipMemcpyHostToDevice));
+        const RenderProgress pg{fn, user};
+        rc = do_render(scene, camera, params, (v4 *)scene->film_tmp.p, nullptr, nullptr, stats, nullptr, &pg, film_inout);
+        if (rc != PTRS_OK) return rc;
+        HIPCHK(hipMemcpy(film_inout + off, (PtrsFilmPixel *)scene->film_tmp.p + off, cnt * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost));
+        return PTRS_OK;
+    });
 }
 
 // ---- one process, N devices ---------------------------------------------------------------------------

@@ -210,6 +210,20 @@ class PathIntegrator:
         self.last_stats = stats
         return stats
 
+    def render_progressive(self, camera, scene, on_pass, row_begin=0, row_end=0):
+        """ptrs_render_progressive: like render(), and after every pass of the pipeline the rows it touched are copied into
+        camera.film.pixels and on_pass(passes_done, passes_total, row_begin, row_end) is called (the preview hook the
+        reference's headless front-end gets by polling its film, headless.rs:197-214)."""
+        ds = _device_scene(scene, self.device)
+        p = self.params(camera, row_begin, row_end)
+        cam = camera.to_abi()
+        stats = abi.PtrsStats()
+        cb_t = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32)
+        cb = cb_t(lambda _u, done, total, y0, y1: on_pass(done, total, y0, y1))
+        _check(load_library().ptrs_render_progressive(ds.handle, C.byref(cam), C.byref(p), C.c_void_p(camera.film.pixels.ctypes.data), cb, None, C.byref(stats)))
+        self.last_stats = stats
+        return stats
+
     def render_multi(self, camera, scene, devices, bounds=None, row_cost=None):
         """ptrs_render_multi: the frame's rows split over `devices` (one PtrsScene per entry, one host thread each, bands
         gathered on the first device); bounds = n+1 row numbers, or planned by ptrs_plan_bands (weighted by row_cost when

@@ -352,6 +352,28 @@ def test_cfg4_classroom_band_at_full_settings(ptrs, scenes):
     _band_vs_fixture(ptrs, cam, scene, 128, "classroom")
 
 
+def test_progressive_render_publishes_the_film_pass_by_pass(ptrs):
+    """ptrs_render_progressive: after each pass the touched rows are in the host film (weights grow from pass to pass), the
+    callback sees every pass once, and the final film is bit-identical to ptrs_render's."""
+    cam, scene = ptrs.import_scene(CORNELL, (64, 48))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(16, cam.film.get_sample_bounds()), 6, paths_per_pass=20000)  # several passes
+    integ.render(cam, scene)
+    ref = cam.film.pixels.copy()
+    n_ref = integ.last_stats.passes
+    cam.film.clear()
+    seen, sums = [], []
+
+    def on_pass(done, total, y0, y1):
+        seen.append((done, total, y0, y1))
+        sums.append(float(cam.film.pixels["weight"].sum()))
+    integ.render_progressive(cam, scene, on_pass)
+    assert [d for d, _, _, _ in seen] == list(range(1, n_ref + 1)) and all(t == n_ref for _, t, _, _ in seen) and n_ref >= 4
+    assert all(0 <= y0 < y1 <= 48 for _, _, y0, y1 in seen)
+    assert all(b > a for a, b in zip(sums, sums[1:])) and sums[0] > 0
+    assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), ref["weight"].view(np.uint32))
+
+
 def test_multi_device_render_is_bit_identical(ptrs):
     """ptrs_render_multi (one process, one host thread and one scene replica per device, bands gathered with device
     copies): 2 and 3 replicas -- all on the one GPU of this box -- with equal and with cost-weighted bands must reproduce
