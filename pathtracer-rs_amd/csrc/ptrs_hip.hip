@@ -43,6 +43,8 @@ struct Options {
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
     int vote = -1;            // lane-refill traversal kernels: each step runs the phase (node visit / triangle test) most lanes of the wave are in.
                               // -1 = by scene: on for quad-form scenes (colonnade extend 86 -> 56 ms), off for LDS-resident pair form, whose cheap steps do not pay for the vote (Cornell 88 -> 92 ms)
+    int fused_epilogue = 1;   // k_extend_rf / k_connect_rf run their segment's epilogue (emission, depth cut, material bucketing) / MIS resolve behind their last ray; 0: the separate k_epilogue / k_resolve
+    int fused_resolve = 1;    // (with fused_epilogue) k_connect_rf resolves its MIS records itself
     int shade_lds = 1;        // shade kernels read light records, small scenes' triangle records and the round's Sobol' tables from LDS (0: everything from global memory)
     int workspace_pct = 40;   // the render workspace (path state + queues of all lanes) may take this share of the device memory that is free at the call
 };
@@ -52,7 +54,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, 0, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 1}, {"shade_lds", &Options::shade_lds, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
+    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 1}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -281,14 +283,20 @@ __device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur,
     }
 }
 
+template <int FEAT>
+__device__ inline void epilogue_segment(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t *lcount); // below, with k_epilogue
+template <int FEAT>
+__device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap); // below, with k_resolve
+
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
-__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8; // quad form with the small stack column: the tree's top lives in LDS
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
-    __shared__ uint32_t cursor;
+    __shared__ uint32_t cursor, lcount[8];
     GeomLocal GL; const GeomGlobal GG0 = geom_global(sc);
     if (threadIdx.x == 0) cursor = 0;
+    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
     GeomTop GG; GG.top = (lds_v4 *)lds_geom; GG.nodesv = GG0.nodesv; GG.tris = GG0.tris; GG.ktop = 0;
     if (TOP) { GG.ktop = sc.n_nodes4 < QUAD_TOP_NODES ? sc.n_nodes4 : (uint32_t)QUAD_TOP_NODES; for (uint32_t i = threadIdx.x; i < 8u * GG.ktop; i += BLOCK) lds_geom[i] = GG0.nodesv[i]; }
     if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
@@ -327,6 +335,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
         // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
         } while (VOTE && __any(has && r_cur != REF_NONE) && (dry || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
     }
+    // The segment's epilogue runs here, behind the workgroup's last ray, unless kinds_mask = 0 leaves it to k_epilogue: the hits
+    // it reads were written a moment ago by this workgroup (L2), and its memory latency hides behind the other workgroups'
+    // traversal instead of filling a kernel of its own.
+    if (kinds_mask) { __syncthreads(); epilogue_segment<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, lcount); }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
 // ray (closest hit) of its record and leaves the answers in the path state (NEE_OCCLUDED in nee2.w, the MIS hit in
 // `hit`, which the shade stage has consumed by now); k_resolve turns them into radiance with full waves.
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
-__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh) {
+__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t fused_resolve) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8;
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
@@ -394,12 +406,14 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
         // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
         } while (VOTE && __any(has && r_cur != REF_NONE) && (dry || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
     }
+    // records with a MIS ray are resolved behind the workgroup's last ray (see k_extend_rf's epilogue), unless fused_resolve = 0 leaves them to k_resolve
+    if (fused_resolve) { __syncthreads(); resolve_segment<FEAT>(sc, P, Q, it, seg_cap); }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
 // estimate_direct's use of the two answers (integrator.rs:66-78, 121-134) and `l += beta * nLights * ld`, full waves
 template <int FEAT>
-__global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
+__device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap) {
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
@@ -413,14 +427,14 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues 
         resolve_item<FEAT>(sc, P, pid, (fl & NEE_OCCLUDED) != 0, mh);
     }
 }
-
-// The epilogue k_extend_rf leaves out: emission / environment / depth cut (integrator.rs:418-431) and material bucketing,
-// one full wave per 64 queue entries.
 template <int FEAT>
-__global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
-    __shared__ uint32_t lcount[8];
-    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
-    __syncthreads();
+__global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) { resolve_segment<FEAT>(sc, P, Q, it, seg_cap); }
+
+// The epilogue of one queue segment, full waves: emission / environment / depth cut (integrator.rs:418-431) and material
+// bucketing, in queue order (the shade stage's state gathers coalesce only while a segment keeps its paths in slot order).
+// lcount: 8 zeroed LDS counters of the workgroup.
+template <int FEAT>
+__device__ inline void epilogue_segment(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t *lcount) {
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_EXT, G, b);
@@ -442,6 +456,15 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
     }
     __syncthreads();
     if (threadIdx.x < 6 && (kinds_mask & (1u << threadIdx.x))) *seg_count(Q, it, Q_MAT0 + (int)threadIdx.x, G, b) = lcount[threadIdx.x];
+}
+
+// The epilogue k_extend_rf leaves out when it does not run it itself (option fused_epilogue = 0).
+template <int FEAT>
+__global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
+    __shared__ uint32_t lcount[8];
+    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
+    __syncthreads();
+    epilogue_segment<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, lcount);
 }
 
 
@@ -936,13 +959,15 @@ struct HipBackend {
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill) {
-#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); else hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill); } while (0)
+            const uint32_t epi_mask = opt.fused_epilogue ? kinds_mask : 0u; // non-zero: the kernel runs its segment's epilogue behind its last ray
+#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill, epi_mask); else hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill, epi_mask); } while (0)
             if (ps->stack_lds == 8) {
                 if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
                 else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
                 else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
             } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
+            if (epi_mask) return;
             t1(); t0(T_AUX); // the traversal span ends here: the epilogue is shading-side work
             hipLaunchKernelGGL((k_epilogue<FEAT>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
             return;
@@ -962,13 +987,15 @@ struct HipBackend {
         const bool ovf = sp.p != nullptr;
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill_connect) {
-#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect); else hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect); } while (0)
+            const uint32_t fused = (opt.fused_epilogue && opt.fused_resolve) ? 1u : 0u;
+#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); else hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); } while (0)
             if (ps->stack_lds == 8) {
                 if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
                 else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
                 else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
             } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
+            if (fused) return;
             t1(); t0(T_AUX);
             hipLaunchKernelGGL((k_resolve<FEAT>), g, b, 0, stream, sc, P, Q, it, seg_cap);
             return;

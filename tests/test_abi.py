@@ -53,3 +53,22 @@ def test_sampler_builder_mirror(ptrs):
     assert (sb.samples_per_pixel, sb.resolution, sb.log_2_resolution) == (128, 2048, 11)
     sb = ptrs.SamplerBuilder(16, (-2, -2, 258, 258))
     assert (sb.samples_per_pixel, sb.resolution, sb.log_2_resolution) == (16, 512, 9)
+
+
+def test_options_api():
+    """ptrs_set_option / ptrs_get_option: known names round-trip, ranges are enforced, unknown names are errors -- no GPU needed.
+    (The library reads no environment variables; these knobs replace the getenv switches of round 1.)"""
+    import importlib
+    ptrs = importlib.import_module("pathtracer-rs_amd")
+    L = ptrs.load_library()
+    defaults = {"lanes": 3, "refill": 16, "refill_connect": 16, "vote": -1, "shade_lds": 1, "fused_epilogue": 1, "fused_resolve": 1, "stack_lds": 8, "grid_mult": 1, "node_form": 0, "workspace_pct": 40}
+    for k, v in defaults.items():
+        assert ptrs.get_option(k) == v, k
+    with ptrs.options(lanes=1, vote=0):
+        assert ptrs.get_option("lanes") == 1 and ptrs.get_option("vote") == 0
+    assert ptrs.get_option("lanes") == 3 and ptrs.get_option("vote") == -1
+    for name, bad in (("lanes", 0), ("lanes", 5), ("workspace_pct", 0), ("vote", 2), ("no_such_option", 1)):
+        assert L.ptrs_set_option(name.encode(), bad) != 0
+        assert L.ptrs_last_error()
+    import ctypes as C
+    assert L.ptrs_get_option(b"no_such_option", C.byref(C.c_int64())) != 0
