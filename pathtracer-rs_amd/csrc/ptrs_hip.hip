@@ -380,8 +380,12 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
                 has = false;
             }
         }
+        // Ray setup (five divisions) is the expensive part of taking a ray, and it runs with the lanes that need it only: a lane
+        // whose shadow ray is done waits for its MIS ray's setup until the idle and the waiting lanes together reach the refill
+        // threshold (or nobody else is working), so that one pass of the setup code serves a batch of lanes, not one or two.
         const unsigned long long idle = __ballot(!has);
-        if (!dry && (uint32_t)__popcll(idle) >= thresh) {
+        const bool batch = (uint32_t)__popcll(__ballot(!has || setup)) >= thresh || !__any(has && !setup);
+        if (batch && !dry && idle) {
             if (!has) {
                 const uint32_t i = rf_take(&cursor, idle);
                 if (i < n) {
@@ -392,9 +396,11 @@ __global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, Stac
             }
             if (cursor >= n) dry = true;
         }
-        if (setup) {
-            if (shadow_phase) { const v4 o = P.sh_o[pid], d = P.sh_d[pid]; if (fl & NEE_PRE) { pre_c = P.nee0[pid]; pre_l = P.L[pid]; } RF_START(xyz(o), xyz(d), o.w) }
-            else { const v4 o = P.mis_o[pid], d = P.mis_d[pid]; RF_START(xyz(o), xyz(d), PT_INF) }
+        if (batch && setup) {
+            const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
+            const v4 o = po[pid], d = pd[pid];
+            if (shadow_phase && (fl & NEE_PRE)) { pre_c = P.nee0[pid]; pre_l = P.L[pid]; }
+            RF_START(xyz(o), xyz(d), shadow_phase ? o.w : PT_INF)
             stk.clear(); setup = false;
         }
         if (!__any(has)) break;
@@ -485,7 +491,13 @@ template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT ==
 //   * the triangles' shading records when the scene has <= SH_TRI_V4 / 13 triangles (Cornell: 36),
 //   * the Sobol' tables of the dimensions this round can draw, in nibble form (16 words per index nibble and dimension):
 //     a sample is scramble ^ XOR of 8 (32-bit index) or 13 LDS words instead of 4 or 8 words gathered from L2.
-enum : uint32_t { SH_SOB_WORDS = 6144, SH_TRI_V4 = 1024, SH_LIGHTS = 16, SH_LIGHT_V4 = sizeof(DLight) / 16, SH_TRI_REC_V4 = sizeof(DTriShade) / 16 };
+#ifndef PTRS_SH_SOB_WORDS
+#define PTRS_SH_SOB_WORDS 6144
+#endif
+#ifndef PTRS_SH_TRI_V4
+#define PTRS_SH_TRI_V4 1024
+#endif
+enum : uint32_t { SH_SOB_WORDS = PTRS_SH_SOB_WORDS, SH_TRI_V4 = PTRS_SH_TRI_V4, SH_LIGHTS = 16, SH_LIGHT_V4 = sizeof(DLight) / 16, SH_TRI_REC_V4 = sizeof(DTriShade) / 16 };
 static_assert(sizeof(DLight) % 16 == 0 && sizeof(DTriShade) % 16 == 0, "records are staged as 16-byte vectors");
 struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds; }; // Sobol' window [sob_lo, sob_lo + sob_n), nibbles staged per dimension
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
@@ -515,8 +527,22 @@ struct ShadeCtxLds {
 #pragma unroll
         for (int k = 0; k < N; ++k) in = in && dim[k] - cfg.sob_lo < cfg.sob_n;
         if (!in) { sobol_batch<N>(S, index, dim, scramble, out); return; } // outside this round's window: the global tables
-        const uint32_t stride = sob_stride(cfg.sob_nib);
         uint32_t v[N];
+        bool run = cfg.sob_nib == 8u; // the common case: N consecutive dimensions, 8 nibbles staged
+#pragma unroll
+        for (int k = 1; k < N; ++k) run = run && dim[k] == dim[0] + (uint32_t)k;
+        if (run) { // one address per index nibble, the dimension is a compile-time offset of the LDS read
+            constexpr uint32_t ST = 8u * 16u + 4u; // sob_stride(8)
+            lds_u32 *t = sob + (dim[0] - cfg.sob_lo) * ST;
+            lds_u32 *t0 = t + (lo & 15u), *t1 = t + 16u + ((lo >> 4) & 15u), *t2 = t + 32u + ((lo >> 8) & 15u), *t3 = t + 48u + ((lo >> 12) & 15u), *t4 = t + 64u + ((lo >> 16) & 15u),
+                    *t5 = t + 80u + ((lo >> 20) & 15u), *t6 = t + 96u + ((lo >> 24) & 15u), *t7 = t + 112u + (lo >> 28);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = scramble ^ t0[k * ST] ^ t1[k * ST] ^ t2[k * ST] ^ t3[k * ST] ^ t4[k * ST] ^ t5[k * ST] ^ t6[k * ST] ^ t7[k * ST];
+#pragma unroll
+            for (int k = 0; k < N; ++k) out[k] = min_(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
+            return;
+        }
+        const uint32_t stride = sob_stride(cfg.sob_nib);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             lds_u32 *t = sob + (dim[k] - cfg.sob_lo) * stride;
