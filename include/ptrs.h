@@ -222,7 +222,10 @@ typedef struct PtrsScene PtrsScene;
 /* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-4 concurrent
  * pipeline lanes, default 3), "refill" / "refill_connect" (idle-lane threshold of the lane-refill traversal
  * kernels, 0 = fused kernels, refill_connect -1 = by scene), "vote" (phase voting in the lane-refill
- * traversal kernels: 0 off, 1 on, -1 = by scene), "stack_lds" (8 or 16 LDS stack entries per lane), "grid_mult", "shade_lds" (0/1: shade kernels read their small tables from LDS), "node_form" (0 auto, 2 force
+ * traversal kernels: 0 off, 1 on, 2 extension kernel only, -1 = by scene), "stack_lds" (8 or 16 LDS stack
+ * entries per lane), "grid_mult", "shade_lds" (0/1: shade kernels read their small tables from LDS),
+ * "fused_epilogue" / "fused_resolve" (0/1: the traversal kernels run the segment's epilogue / MIS resolve
+ * behind their last ray instead of separate k_epilogue / k_resolve launches), "node_form" (0 auto, 2 force
  * quad nodes), "workspace_pct" (share of the free device memory the render workspace may take, default
  * 40).  None of them changes a result bit; they select between equivalent schedules.  Scene-level knobs
  * (node_form, stack_lds, grid_mult) are read by ptrs_scene_create, the rest by each render call.

@@ -42,7 +42,8 @@ struct Options {
     int grid_mult = 1;        // workgroups per pass in units of the resident capacity (8 per CU)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
     int vote = -1;            // lane-refill traversal kernels: each step runs the phase (node visit / triangle test) most lanes of the wave are in.
-                              // -1 = by scene: on for quad-form scenes (colonnade extend 86 -> 56 ms), off for LDS-resident pair form, whose cheap steps do not pay for the vote (Cornell 88 -> 92 ms)
+                              // 0 off, 1 both kernels, 2 extension kernel only, -1 = by scene: 1 for quad-form scenes (colonnade extend 86 -> 56 ms), 2 for the LDS-resident
+                              // pair form, whose cheap steps do not pay for the vote in the connect kernel (Cornell: extend 92.5 -> 89 ms, connect 52 -> 63 ms)
     int fused_epilogue = 1;   // k_extend_rf / k_connect_rf run their segment's epilogue (emission, depth cut, material bucketing) / MIS resolve behind their last ray; 0: the separate k_epilogue / k_resolve
     int fused_resolve = 1;    // (with fused_epilogue) k_connect_rf resolves its MIS records itself
     int shade_lds = 1;        // shade kernels read light records, small scenes' triangle records and the round's Sobol' tables from LDS (0: everything from global memory)
@@ -54,7 +55,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, 0, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 1}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
+    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -892,7 +893,7 @@ struct HipBackend {
     }
     int grid_max = 2048;
     uint32_t refill_connect = 16;
-    bool vote = true;
+    bool vote = true, vote_connect = true;
     uint32_t refill = 16; // idle-lane threshold of the lane-refill kernels; 0 = the fused k_extend / k_connect (PTRS_REFILL)
     int rc = PTRS_OK;
     // timing
@@ -935,7 +936,10 @@ struct HipBackend {
         // colonnade (quad form) none 1517, extend 1698, both 1830
         refill_connect = (uint32_t)(opt.refill_connect < 0 ? 16 : opt.refill_connect);
         refill = (uint32_t)opt.refill;
-        vote = opt.vote >= 0 ? opt.vote != 0 : sc.n_nodes4 != 0;
+        // phase voting: quad-node scenes gain in both traversal kernels; on the LDS pair form a step is cheap enough that the vote's
+        // own instructions eat the gain in the connect kernel (+20 %), the extension kernel keeps 4 % (A/B on MI355X)
+        vote = opt.vote >= 0 ? opt.vote != 0 : true;
+        vote_connect = opt.vote >= 0 ? opt.vote == 1 : sc.n_nodes4 != 0;
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
@@ -1014,7 +1018,7 @@ struct HipBackend {
         if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
         if (refill_connect) {
             const uint32_t fused = (opt.fused_epilogue && opt.fused_resolve) ? 1u : 0u;
-#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); else hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); } while (0)
+#define PTRS_LAUNCH(D, O, GE) do { if (vote_connect) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); else hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); } while (0)
             if (ps->stack_lds == 8) {
                 if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
                 else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }

@@ -67,7 +67,7 @@ def test_options_api():
     with ptrs.options(lanes=1, vote=0):
         assert ptrs.get_option("lanes") == 1 and ptrs.get_option("vote") == 0
     assert ptrs.get_option("lanes") == 3 and ptrs.get_option("vote") == -1
-    for name, bad in (("lanes", 0), ("lanes", 5), ("workspace_pct", 0), ("vote", 2), ("no_such_option", 1)):
+    for name, bad in (("lanes", 0), ("lanes", 5), ("workspace_pct", 0), ("vote", 3), ("no_such_option", 1)):
         assert L.ptrs_set_option(name.encode(), bad) != 0
         assert L.ptrs_last_error()
     import ctypes as C

@@ -156,12 +156,12 @@ def test_traversal_kernel_variants_give_the_same_samples(ptrs, orc, scenes):
     the shade kernels, fused_epilogue = 0 the separate k_epilogue / k_resolve passes; any combination and any idle-lane
     threshold must give the same samples."""
     cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
-    for ext, con, vote, lds in ((0, 0, 1, 1), (1, 1, 1, 1), (0, 16, 0, 0), (64, 0, 1, 1), (16, 16, 0, 1), (16, 16, 1, 0), (48, 48, 1, 1)):
+    for ext, con, vote, lds in ((0, 0, 1, 1), (1, 1, 1, 1), (0, 16, 0, 0), (64, 0, 1, 1), (16, 16, 0, 1), (16, 16, 1, 0), (48, 48, 1, 1), (16, 16, 2, 1), (16, 16, -1, 1)):
         with ptrs.options(refill=ext, refill_connect=con, vote=vote, shade_lds=lds, fused_epilogue=lds):
             _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
     # and on an LDS-resident (pair-form) scene
     cam, scene = ptrs.import_scene(CORNELL, (48, 48))
-    for ext, con, vote, lds in ((0, 0, 1, 1), (16, 16, 0, 0), (16, 16, 1, 1), (16, 0, 1, 0), (16, 0, 0, 1)):
+    for ext, con, vote, lds in ((0, 0, 1, 1), (16, 16, 0, 0), (16, 16, 1, 1), (16, 0, 1, 0), (16, 0, 0, 1), (16, 16, 2, 1), (16, 16, -1, 1)):
         with ptrs.options(refill=ext, refill_connect=con, vote=vote, shade_lds=lds, fused_epilogue=lds):
             _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
 
