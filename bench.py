@@ -147,11 +147,13 @@ def load_pmc(workload):
     for name, k in j.items():
         if name.startswith("_"):
             continue
-        c = cls.setdefault(kernel_class(name), dict(launches=0.0, hbm_bytes=0.0, valu_insts=0.0, lane_insts=0.0, kernels=[]))
+        c = cls.setdefault(kernel_class(name), dict(launches=0.0, hbm_bytes=0.0, valu_insts=0.0, lane_insts=0.0, busy_ms=0.0, total_ms=0.0, kernels=[]))
         c["launches"] += k["calls"] / frames
         c["hbm_bytes"] += k["hbm_bytes"] / frames
         c["valu_insts"] += k["valu_insts"] / frames
         c["lane_insts"] += k["valu_insts"] * k["lanes_per_valu_inst"] / frames
+        c["busy_ms"] += k.get("valu_busy_frac", 0.0) * k["total_ms"] / frames
+        c["total_ms"] += k["total_ms"] / frames
         c["kernels"].append(name)
     return cls, meta
 
@@ -179,6 +181,9 @@ def class_roofline(name, ms_excl, launches_excl, ms_timed, launches_timed, pmc, 
         r["valu_issue_frac"] = (c["valu_insts"] / sec) / (VALU_PEAK_TLANEOPS * 1e12 / 64.0)
         r["valu_tlaneops"] = c["lane_insts"] / sec / 1e12
         r["valu_lane_frac"] = r["valu_tlaneops"] / VALU_PEAK_TLANEOPS
+        # share of the profiled kernel time the SIMDs' VALU pipes were executing (4 x SQ_ACTIVE_INST_VALU / SIMDs / GRBM cycles, from the
+        # profiled run): a plain fp32 wave64 instruction occupies the pipe for 4 cycles, only packed / dual-issued ones reach the 2-cycle peak
+        r["valu_pipe_busy_frac_profiled"] = c["busy_ms"] / c["total_ms"] if c["total_ms"] > 0 else None
     return r
 
 
@@ -330,6 +335,7 @@ def main():
             "why": "divergent, latency-exposed scalar code: neither class moves more than a fraction of the HBM peak (hbm_counter_frac) and the tree / path state it reads is served by LDS and L2; what is scarce is VALU issue slots with lanes in them",
             "achieved": d.get("valu_tlaneops"), "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s (active-lane VALU instructions; peak = 1 wave64 instruction / 2 cycles / SIMD at 2.4 GHz = the 157 TFLOP/s fp32 vector peak)",
             "frac": d.get("valu_lane_frac"),
+            "valu_pipe_busy_frac_profiled": d.get("valu_pipe_busy_frac_profiled"),  # the VALU pipes are busy this share of the time; `frac` is lower by the idle lanes and the 4-cycle plain-fp32 issue
             "traffic": d.get("hbm_bytes_per_launch"),
             "hbm": {"achieved": d.get("hbm_counter_gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d.get("hbm_counter_frac"), "what": "FETCH_SIZE + WRITE_SIZE of the class's kernels (committed rocprofv3 PMC passes) / their single-lane duration measured in this run"},
             "algorithmic": {"what": "SURVEY 8(d): 32 B ray in + 32 B per box tested + 48 B per triangle tested + 16 B hit out, x rays / traversal-kernel time; NOT HBM traffic (LDS- and L2-served)",

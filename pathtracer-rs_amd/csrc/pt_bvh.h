@@ -42,16 +42,33 @@ PT_HD bool slab_entry6(float minx, float miny, float minz, float maxx, float max
     float ty_max = ((neg[1] ? miny : maxy) - o.y) * inv.y;
     t_mx *= k; ty_max *= k;
     const bool miss_y = (t_min > ty_max) | (ty_min > t_mx);
-    t_min = ty_min > t_min ? ty_min : t_min;
-    t_mx = ty_max < t_mx ? ty_max : t_mx;
     const float tz_min = ((neg[2] ? maxz : minz) - o.z) * inv.z;
     float tz_max = ((neg[2] ? minz : maxz) - o.z) * inv.z;
     tz_max *= k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // `if ty_min > t_min { t_min = ty_min }` as one v_max_f32 instead of compare + select (and v_min_f32 for the upper ends).  The two forms
+    // differ only when the running value is a NaN, which the comparison keeps and max / min drop: a NaN can only enter the running values
+    // on the x axis (0 * inf: the ray lies in one of the box's x planes), the comparison form then carries it to the end and the box fails
+    // (t_mx > 0 is false for a NaN t_mx; for a NaN t_min the entry distance is NaN and every caller's t_entry < t_max is false).  The
+    // `ordered` test below fails the box in exactly those cases.  A NaN coming in from y or z is dropped by both forms.  (+0 / -0 can come
+    // out differently; the entry distance is only ever compared.)
+    const bool x_ordered = !__builtin_isunordered(t_min, t_mx);
+    t_min = __builtin_fmaxf(t_min, ty_min);
+    t_mx = __builtin_fminf(t_mx, ty_max);
+    const bool miss_z = (t_min > tz_max) | (tz_min > t_mx);
+    t_min = __builtin_fmaxf(t_min, tz_min);
+    t_mx = __builtin_fminf(t_mx, tz_max);
+    t_entry = t_min;
+    return !(miss_y | miss_z) & (t_mx > 0.0f) & x_ordered;
+#else
+    t_min = ty_min > t_min ? ty_min : t_min;
+    t_mx = ty_max < t_mx ? ty_max : t_mx;
     const bool miss_z = (t_min > tz_max) | (tz_min > t_mx);
     t_min = tz_min > t_min ? tz_min : t_min;
     t_mx = tz_max < t_mx ? tz_max : t_mx;
     t_entry = t_min;
     return !(miss_y | miss_z) & (t_mx > 0.0f);
+#endif
 }
 
 // Alpha-mask test of an accepted candidate (shape.rs:227-244 / 470-521): the mask texture is looked up at
@@ -94,10 +111,10 @@ PT_HD void pair_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg
     const bool h0 = slab_entry6(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, neg, t0) & (t0 < t_max);
     const bool h1 = (ref1 != REF_NONE) & slab_entry6(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, neg, t1) & (t1 < t_max);
     const bool second_first = axis < 3u && neg[axis];
-    const uint32_t near_ref = second_first ? ref1 : ref0, far_ref = second_first ? ref0 : ref1;
-    const bool near_hit = second_first ? h1 : h0, far_hit = second_first ? h0 : h1;
-    if (near_hit) { if (far_hit) stack.push(far_ref, second_first ? t0 : t1); cur = near_ref; }
-    else if (far_hit) cur = far_ref;
+    // both hit: the near one is entered, the far one postponed; one hit: that one (whichever side it is on); none: the stack.
+    // (Written on h0 / h1 themselves: a select between two lane masks would be computed on 0/1 integers in vector registers.)
+    if (h0 & h1) { stack.push(second_first ? ref0 : ref1, second_first ? t0 : t1); cur = second_first ? ref1 : ref0; }
+    else if (h0 | h1) cur = h0 ? ref0 : ref1;
     else cur = pop_next_ref<ANY>(stack, t_max);
 }
 
@@ -182,12 +199,16 @@ PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg
     const uint32_t ax = axes & 3u, aa = (axes >> 2) & 3u, ab = (axes >> 4) & 3u;
     const bool sw = ax < 3u && neg[ax], swa = aa < 3u && neg[aa], swb = ab < 3u && neg[ab];
     if (axes & 0x100u) { t0 = t1 = t2 = t3 = -3.402823466e38f; } // chunks of one leaf: no pop-time re-test
-#define PT_SWAP(c, ra, ta, ha, rb, tb, hb) { const uint32_t rr = c ? rb : ra; const float tt = c ? tb : ta; const bool hh = c ? hb : ha; rb = c ? ra : rb; tb = c ? ta : tb; hb = c ? ha : hb; ra = rr; ta = tt; ha = hh; }
-    PT_SWAP(swa, r0, t0, h0, r1, t1, h1)
-    PT_SWAP(swb, r2, t2, h2, r3, t3, h3)
-    PT_SWAP(sw, r0, t0, h0, r2, t2, h2)
-    PT_SWAP(sw, r1, t1, h1, r3, t3, h3)
+    // A slot that is not hit loses its reference, so that the reordering below moves two values per slot, not two values and a
+    // lane mask (a select between lane masks is computed on 0/1 integers in vector registers); hit <=> reference left.
+    r0 = h0 ? r0 : REF_NONE; r1 = h1 ? r1 : REF_NONE; r2 = h2 ? r2 : REF_NONE; r3 = h3 ? r3 : REF_NONE;
+#define PT_SWAP(c, ra, ta, rb, tb) { const uint32_t rr = c ? rb : ra; const float tt = c ? tb : ta; rb = c ? ra : rb; tb = c ? ta : tb; ra = rr; ta = tt; }
+    PT_SWAP(swa, r0, t0, r1, t1)
+    PT_SWAP(swb, r2, t2, r3, t3)
+    PT_SWAP(sw, r0, t0, r2, t2)
+    PT_SWAP(sw, r1, t1, r3, t3)
 #undef PT_SWAP
+    h0 = r0 != REF_NONE; h1 = r1 != REF_NONE; h2 = r2 != REF_NONE; h3 = r3 != REF_NONE;
     // visiting order is now 0,1,2,3: the first hit is entered, later hits are stacked last-first
     if (h3 && (h0 || h1 || h2)) stack.push(r3, t3);
     if (h2 && (h0 || h1)) stack.push(r2, t2);

@@ -150,6 +150,47 @@ def test_stack_spill_path_matches_oracle(ptrs, orc, scenes):
     assert np.array_equal(hg["prim"], ho["prim"]) and np.array_equal(hg["t"].view(np.uint32), ho["t"].view(np.uint32))
 
 
+def _lattice_scene(ptrs, n):
+    """n^3 axis-aligned unit squares on integer planes (two triangles each): every box face of the tree lies in a coordinate plane."""
+    s = ptrs.RenderScene()
+    m = s.add_material(ptrs.abi.MAT_MATTE, [s.const_rgb([0.5, 0.5, 0.5])])
+    pos, idx = [], []
+    for i in range(n):
+        for j in range(n):
+            for k in range(n):
+                ax = (i + j + k) % 3
+                o = np.array([i, j, k], np.float32) * 2.0
+                u, v = np.eye(3, dtype=np.float32)[(ax + 1) % 3], np.eye(3, dtype=np.float32)[(ax + 2) % 3]
+                b = len(pos)
+                pos += [o, o + u, o + u + v, o + v]
+                idx += [[b, b + 1, b + 2], [b, b + 2, b + 3]]
+    s.add_mesh(np.array(pos, np.float32), np.array(idx, np.uint32), m)
+    return s
+
+
+def test_rays_inside_box_planes(ptrs, orc):
+    """Rays with zero direction components that start exactly in the planes of the tree's boxes: (plane - o) * (1 / 0) is
+    0 * inf = NaN in the slab test.  The reference's compare-and-assign form keeps such a NaN, the kernels' v_max / v_min form
+    needs its explicit `ordered` test to fail the same boxes (pt_bvh.h slab_entry6).  Pair form (3^3 squares fit LDS) and quad form."""
+    dirs = np.array([[a, b, c] for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)], np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    for n, form in ((3, 0), (3, 2), (6, 0)):
+        with ptrs.options(node_form=form):
+            scene = _lattice_scene(ptrs, n)
+            g = np.arange(-1, 2 * n + 1, 0.5, dtype=np.float32)
+            rng = np.random.default_rng(11 + n)
+            o = rng.choice(g, (6000, 3))
+            d = dirs[rng.integers(0, len(dirs), 6000)]
+            rays = np.concatenate([o, d, np.full((6000, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+            hg, _ = ptrs.trace_rays(scene, rays)
+            ho, _ = orc.OracleScene(scene).trace_rays(rays)
+            assert (ho["prim"] >= 0).sum() > 500
+            assert np.array_equal(hg["prim"], ho["prim"]) and np.array_equal(hg["t"].view(np.uint32), ho["t"].view(np.uint32))
+            occ, _ = ptrs.trace_rays(scene, rays, any_hit=True)
+            oco, _ = orc.OracleScene(scene).trace_rays(rays, any_hit=True)
+            assert np.array_equal(occ["prim"] >= 0, oco["prim"] >= 0)
+
+
 def test_traversal_kernel_variants_give_the_same_samples(ptrs, orc, scenes):
     """The options refill / refill_connect = 0 select the fused k_extend / k_connect instead of the lane-refill kernels
     (+ k_epilogue / k_resolve), vote = 0 the while-while loop instead of phase voting, shade_lds = 0 global-memory tables in
