@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--paths-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--even-bands", action="store_true", help="N > 1: bands of equal height instead of equal cost")
     ap.add_argument("--profile", action="store_true", help="for rocprofv3 runs: render exactly --steps frames on ONE pipeline lane (no counter / warm-up frames, no JSON)")
     ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS),
                     help="cornell = BASELINE configs[1] (the headline); colonnade / classroom = synthetic stand-ins for configs[2] / [3]")
@@ -248,7 +249,15 @@ def main():
     standard = (spp, (W, H), args.depth, args.paths_per_pass) == (wl["spp"], wl["res"], DEPTH, 0)
     integ = pkg.PathIntegrator(pkg.SamplerBuilder(spp, cam.film.get_sample_bounds()), args.depth, device=local_rank, paths_per_pass=args.paths_per_pass)
     integ.preprocess(scene)
-    row_b, row_e = par.band_for_rank(H, rank, world)
+    # N > 1: bands of equal cost (per-row ray counts of an untimed 1-spp probe; every rank computes the same plan), unless --even-bands
+    bounds, probe_ms = None, 0.0
+    if world > 1 and not args.even_bands:
+        tp = time.perf_counter()
+        bounds = par.plan_bands(H, world, par.probe_row_cost(pkg, cam, scene, args.depth, device=local_rank, strips=64, spp=1))
+        probe_ms = (time.perf_counter() - tp) * 1e3
+        row_b, row_e = bounds[rank], bounds[rank + 1]
+    else:
+        row_b, row_e = par.band_for_rank(H, rank, world)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -257,10 +266,10 @@ def main():
         st = integ.render_device(cam, scene, film.data_ptr(), stream=stream, row_begin=row_b, row_end=row_e, flags=flags)
         if world > 1:
             if backend == "nccl":
-                par.gather_film_rows(film, H, rank, world)
+                par.gather_film_rows(film, H, rank, world, bounds=bounds)
             else:  # CPU-staged gather (rehearsal only)
                 host = film.cpu()
-                par.gather_film_rows(host, H, rank, world)
+                par.gather_film_rows(host, H, rank, world, bounds=bounds)
                 if rank == 0:
                     film.copy_(host)
         return st
@@ -369,6 +378,7 @@ def main():
             "dtype": "f32", "data": "synthetic (%s, deterministic Sobol sequence)" % ("data/cornell-box.xml as parsed" if args.workload == "cornell" else "procedural %s scene, seeded" % args.workload),
             "config": {"workload": wl["label"] % (W, H, spp, args.depth),
                        "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world,
+                       "band_plan": ("single band" if world == 1 else ("equal height" if bounds is None else "equal cost (1-spp probe in 64 strips, %.0f ms, untimed setup): rows %s" % (probe_ms, bounds))),
                        "collective": ("none" if world == 1 else ("rccl gather of film row bands" if backend == "nccl" else backend + " gather (host-staged fallback, NOT an RCCL number)")),
                        "halo_overhead": rows_traced / float(H + 4) - 1.0, "rays_traced_incl_halo_per_step": rays_traced / args.steps,
                        "pipeline_lanes": lanes},

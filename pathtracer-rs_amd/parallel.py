@@ -3,7 +3,9 @@ output rows per rank, one gather of the bands to rank 0 over RCCL (torch.distrib
 "nccl") at the end of the render.  Each sample depends only on (pixel, sample index) -- the sampler
 ignores the tile seed (sampler/sobol.rs:75-77) -- so ranks exchange nothing while tracing; a rank
 re-traces the 2-row filter halo on each side of its band (film.rs:60-106) so that its rows are
-complete and bit-identical to the single-GPU render."""
+complete and bit-identical to the single-GPU render.  Bands are equal in height (band_for_rank) or equal in
+cost (plan_bands over probe_row_cost: rows differ in work -- Cornell's most expensive eighth costs 1.11 x
+the mean -- and the frame is done when the slowest rank is)."""
 import torch
 import torch.distributed as dist
 
@@ -15,14 +17,50 @@ def band_for_rank(height, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_film_rows(film, height, rank, world, group=None, dst=0):
-    """film: (H, W, 4) tensor whose rows band_for_rank(H, rank, world) are valid on this rank.
-    After the call rank `dst` holds the complete film.  One collective (gather) of equal-size
+def plan_bands(height, world, row_cost=None):
+    """world + 1 row numbers cutting [0, height) into contiguous bands: equal heights, or -- with one cost per row -- equal
+    cost (ptrs_plan_bands, the planner the C++ host's N-device render uses).  Deterministic: every rank that computes it
+    from the same costs gets the same plan."""
+    import ctypes as C
+    import numpy as np
+    from .integrator import load_library, _check
+    b = (C.c_int32 * (int(world) + 1))()
+    rc = None if row_cost is None else np.ascontiguousarray(row_cost, dtype=np.float32)
+    if rc is not None and rc.shape[0] != int(height):
+        raise ValueError("row_cost needs one entry per film row")
+    _check(load_library().ptrs_plan_bands(int(height), int(world), C.c_void_p(rc.ctypes.data) if rc is not None else None, b))
+    return [int(v) for v in b]
+
+
+def probe_row_cost(pkg, camera, scene, max_depth, device=0, strips=64, spp=1):
+    """Per-row cost estimate for plan_bands: the frame at `spp` samples per pixel in `strips` horizontal strips, cost of a
+    row = BVH queries of its strip / rows of the strip (what PathIntegrator::render_multi's probe_row_cost does in the C++
+    host).  Ray counts are deterministic, so every rank gets the same numbers without talking to the others."""
+    import numpy as np
+    h, w = camera.film.height, camera.film.width
+    integ = pkg.PathIntegrator(pkg.SamplerBuilder(spp, camera.film.get_sample_bounds()), max_depth, device=device)
+    scratch = torch.zeros((h, w, 4), dtype=torch.float32, device=torch.device("cuda", device))
+    strips = max(1, min(int(strips), h))
+    cost = np.zeros(h, np.float32)
+    for k in range(strips):
+        b, e = h * k // strips, h * (k + 1) // strips
+        if e <= b:
+            continue
+        st = integ.render_device(camera, scene, scratch.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, row_begin=b, row_end=e)
+        cost[b:e] = float(st.rays_extension + st.rays_shadow + st.rays_mis) / (e - b)
+    torch.cuda.synchronize()
+    return cost
+
+
+def gather_film_rows(film, height, rank, world, group=None, dst=0, bounds=None):
+    """film: (H, W, 4) tensor whose rows of this rank's band are valid (band_for_rank, or bounds[rank]:bounds[rank + 1] when
+    a plan is given).  After the call rank `dst` holds the complete film.  One collective (gather) of equal-size
     slabs; unequal bands are padded to the largest band."""
     if world == 1:
         return film
-    max_rows = -(-int(height) // int(world))
-    b, e = band_for_rank(height, rank, world)
+    band = (lambda r: (int(bounds[r]), int(bounds[r + 1]))) if bounds is not None else (lambda r: band_for_rank(height, r, world))
+    max_rows = max(band(r)[1] - band(r)[0] for r in range(world))
+    b, e = band(rank)
     if e - b == max_rows:
         send = film[b:e]
     else:
@@ -35,7 +73,7 @@ def gather_film_rows(film, height, rank, world, group=None, dst=0):
         for r in range(world):
             if r == dst:
                 continue
-            rb, re = band_for_rank(height, r, world)
+            rb, re = band(r)
             film[rb:re] = bufs[r][: re - rb]
     else:
         dist.gather(send, None, dst=dst, group=group)

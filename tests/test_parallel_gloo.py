@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 from conftest import CORNELL, ROOT
 
 
-def _worker(rank, world, port, w, h, spp, depth, out_path):
+def _worker(rank, world, port, w, h, spp, depth, out_path, bounds=None):
     sys.path.insert(0, ROOT)
     import importlib
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -24,10 +24,10 @@ def _worker(rank, world, port, w, h, spp, depth, out_path):
     par = importlib.import_module("pathtracer-rs_amd.parallel")
     from oracle import orc
     cam, scene = pkg.import_scene(CORNELL, (w, h))
-    b, e = par.band_for_rank(h, rank, world)
+    b, e = (bounds[rank], bounds[rank + 1]) if bounds else par.band_for_rank(h, rank, world)
     film_np, _, _ = orc.OracleScene(scene).render(cam, orc.make_params(w, h, spp, depth, row_begin=b, row_end=e), n_threads=1)
     film = torch.from_numpy(np.concatenate([film_np["rgb"], film_np["weight"][..., None]], axis=-1).copy())
-    par.gather_film_rows(film, h, rank, world)
+    par.gather_film_rows(film, h, rank, world, bounds=bounds)
     if rank == 0:
         np.save(out_path, film.numpy())
     dist.barrier()
@@ -42,11 +42,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_band_gather_equals_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,bounds", [(2, None), (3, None), (2, [0, 5, 22]), (3, [0, 9, 10, 22])])
+def test_band_gather_equals_single_process(tmp_path, world, bounds):
+    """Equal bands and planned (unequal) bands: the gathered film is the single-process film, bit for bit."""
     w, h, spp, depth = 24, 22, 2, 3
     out = str(tmp_path / "film.npy")
-    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, depth, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, depth, out, bounds), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     import importlib
     pkg = importlib.import_module("pathtracer-rs_amd")
@@ -67,3 +68,18 @@ def test_band_partition_covers_rows():
             assert bands[0][0] == 0 and bands[-1][1] == h
             assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
             assert max(e - b for b, e in bands) - min(e - b for b, e in bands) <= 1
+
+
+def test_plan_bands_equal_cost():
+    """parallel.plan_bands (ptrs_plan_bands): contiguous, covering, and with per-row costs no band above 1.25 x the mean cost
+    where equal heights would give 1.6 x."""
+    import importlib
+    par = importlib.import_module("pathtracer-rs_amd.parallel")
+    assert par.plan_bands(10, 3) == [0, 4, 7, 10]
+    h, world = 1024, 8
+    cost = 1.0 + 4.0 * np.exp(-((np.arange(h) - 300.0) / 120.0) ** 2)  # a bump of expensive rows
+    b = par.plan_bands(h, world, cost)
+    assert b[0] == 0 and b[-1] == h and all(b[i] < b[i + 1] for i in range(world))
+    per = np.array([cost[b[i]:b[i + 1]].sum() for i in range(world)])
+    even = np.array([cost[h * i // world:h * (i + 1) // world].sum() for i in range(world)])
+    assert per.max() / per.mean() < 1.25 < even.max() / even.mean()
