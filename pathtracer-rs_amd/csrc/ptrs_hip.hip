@@ -289,8 +289,14 @@ __device__ inline void epilogue_segment(const DParams &R, const DScene &sc, cons
 template <int FEAT>
 __device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap); // below, with k_resolve
 
+// Waves per SIMD the traversal kernels are compiled for.  The quad-form kernels without alpha masks sit at the edge of 96
+// registers (5 waves), and a few registers more cost a wave and 4 % of the kernel's time (colonnade k_connect_rf: 92 -> 101
+// registers, 36.7 -> 38.2 ms): the hint pins them at 5, the small LDS-resident pair form at 6 (74-80 registers).  The others
+// are left to the compiler (0 = no hint): LDS holds them at 4 waves anyway, or the full feature set needs 110-120 registers.
+template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 256 ? 6 : ((GEOM == 0 && DEPTH == 8 && FEAT == FEAT_SIMPLE) ? 5 : 0) }; };
+
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
-__global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask) {
+__global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8; // quad form with the small stack column: the tree's top lives in LDS
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_rf(DParams R, DScene sc, Stack
 // ray (closest hit) of its record and leaves the answers in the path state (NEE_OCCLUDED in nee2.w, the MIS hit in
 // `hit`, which the shade stage has consumed by now); k_resolve turns them into radiance with full waves.
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
-__global__ __launch_bounds__(BLOCK) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t fused_resolve) {
+__global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t fused_resolve) {
     constexpr bool TOP = GEOM == 0 && DEPTH == 8;
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
