@@ -221,7 +221,7 @@ typedef struct PtrsScene PtrsScene;
 
 /* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-4 concurrent
  * pipeline lanes, default 3), "refill" / "refill_connect" (idle-lane threshold of the lane-refill traversal
- * kernels, 0 = fused kernels, refill_connect -1 = by scene), "vote" (phase voting in the lane-refill
+ * kernels, 0 = fused kernels, -1 = by scene), "vote" (phase voting in the lane-refill
  * traversal kernels: 0 off, 1 on, 2 extension kernel only, -1 = by scene), "stack_lds" (8 or 16 LDS stack
  * entries per lane), "grid_mult", "shade_lds" (0/1: shade kernels read their small tables from LDS),
  * "fused_epilogue" / "fused_resolve" (0/1: the traversal kernels run the segment's epilogue / MIS resolve

@@ -36,8 +36,8 @@ thread_local std::string g_err;
 // it needs once; the defaults are the measured best on MI355X.
 struct Options {
     int lanes = 3;            // concurrent pipeline lanes (own path state, queues and stream each), 1..MAX_LANES
-    int refill = 16;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend
-    int refill_connect = 16;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
+    int refill = -1;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend; -1 = by scene (32 with phase voting and no alpha masks, else 16)
+    int refill_connect = -1;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
     int grid_mult = 1;        // workgroups per pass in units of the resident capacity (8 per CU)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
@@ -54,7 +54,7 @@ std::mutex g_opt_mu;
 Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
-    {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, 0, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
+    {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
     {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
 };
 
@@ -940,12 +940,15 @@ struct HipBackend {
         grid_max = ps->n_cu * 8 * ps->grid_mult;
         // measured (single lane, Mray/s): Cornell (pair form, LDS) extend-refill 5722 vs none 5560, with connect-refill 5666;
         // colonnade (quad form) none 1517, extend 1698, both 1830
-        refill_connect = (uint32_t)(opt.refill_connect < 0 ? 16 : opt.refill_connect);
-        refill = (uint32_t)opt.refill;
         // phase voting: quad-node scenes gain in both traversal kernels; on the LDS pair form a step is cheap enough that the vote's
         // own instructions eat the gain in the connect kernel (+20 %), the extension kernel keeps 4 % (A/B on MI355X)
         vote = opt.vote >= 0 ? opt.vote != 0 : true;
         vote_connect = opt.vote >= 0 ? opt.vote == 1 : sc.n_nodes4 != 0;
+        // idle-lane threshold: a voting wave comes back for retire / refill in batches, and with the cheap steps of the kernels without
+        // alpha masks a bigger batch pays (Cornell extend 88.8 -> 85.7 ms, colonnade connect 38.2 -> 36.4 ms at 32); the full-feature
+        // kernels (classroom) are better off at 16 (extend 227 vs 233 ms)
+        refill = (uint32_t)(opt.refill >= 0 ? opt.refill : ((vote && feat_trace == FEAT_SIMPLE) ? 32 : 16));
+        refill_connect = (uint32_t)(opt.refill_connect >= 0 ? opt.refill_connect : ((vote_connect && feat_trace == FEAT_SIMPLE) ? 32 : 16));
         geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
