@@ -102,7 +102,16 @@ int PathIntegrator::render(Camera &camera, RenderScene &scene, PtrsStats *stats)
         gpu_scene_src_ = &scene;
     }
     const PtrsRenderParams p = params(camera);
-    int rc = ptrs_render(gpu_scene_, &camera.abi, &p, camera.film.pixels.data(), stats);
+    int rc;
+    if (on_pass || show_progress_bar_) { // integrator.rs:631-634 (progress bar) / headless.rs:197-214 (film read while rendering): the film is published pass by pass
+        struct Ctx { PathIntegrator *self; } ctx{this};
+        auto thunk = [](void *user, uint32_t done, uint32_t total, int32_t y0, int32_t y1) {
+            PathIntegrator *self = static_cast<Ctx *>(user)->self;
+            if (self->show_progress_bar_) std::fprintf(stderr, "\rrendering: pass %u/%u%s", done, total, done == total ? "\n" : "");
+            if (self->on_pass) self->on_pass(done, total, y0, y1);
+        };
+        rc = ptrs_render_progressive(gpu_scene_, &camera.abi, &p, camera.film.pixels.data(), thunk, &ctx, stats);
+    } else rc = ptrs_render(gpu_scene_, &camera.abi, &p, camera.film.pixels.data(), stats);
     if (rc != PTRS_OK) last_error = ptrs_last_error();
     return rc;
 }

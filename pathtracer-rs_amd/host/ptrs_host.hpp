@@ -15,6 +15,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -91,6 +92,10 @@ public:
     void toggle_progress_bar() { show_progress_bar_ = !show_progress_bar_; }
     // integrator.rs:536-642 on the GPU; accumulates into camera.film.  Returns PTRS_OK or an error code.
     int render(Camera &camera, RenderScene &scene, PtrsStats *stats = nullptr);
+    // When set, render() publishes the film after every pass of the pipeline (ptrs_render_progressive) and calls this with
+    // (passes done, passes in total, first row, one past the last row that changed): the hook a preview gets instead of the
+    // reference's second thread that reads the film every 2 s (headless.rs:197-214).
+    std::function<void(uint32_t, uint32_t, int32_t, int32_t)> on_pass;
     // The same render split over the devices 0 .. n_devices-1 of this process: the scene is uploaded to every
     // device, output rows are cut into one band per device -- weighted by the ray counts of a 1-spp probe when
     // cost_weighted -- and ptrs_render_multi renders the bands on one host thread per device and gathers them.  The film
