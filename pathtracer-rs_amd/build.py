@@ -12,7 +12,11 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptrs_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+# -fno-slp-vectorize: the SLP vectoriser pairs independent binary32 operations into v_pk_mul_f32 / v_pk_add_f32 (20 000 of them in
+# this library); on these kernels a packed instruction costs more than the two plain ones it replaces and the pairing costs
+# registers (k_shade<Matte> 201 -> 183, k_extend_rf pair form 76 -> 64).  Same-box A/B on MI355X: Cornell +3 %, colonnade +4 %,
+# classroom +5 % (its shade kernels -11 %).  Same bits either way.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-parameter"]
 
 
