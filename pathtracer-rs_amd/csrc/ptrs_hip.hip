@@ -482,11 +482,12 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
 
 
 // One instantiation per material kind (and feature set): lobe kinds are compile-time constants.
-// Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X: the Matte / FEAT_SIMPLE kernel (175
-// VGPRs unconstrained -> 2 waves) gains 9 % at 3 waves (168 VGPRs, no scratch growth); the FEAT_FULL kernels (up to 256
-// VGPRs) lose 5 % to spills when pressed to 3 and every kernel loses at 4.
+// Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X.  The Matte / FEAT_SIMPLE kernel needs 183
+// registers unconstrained and fits 168 (3 waves) with 24 bytes of scratch: +1.6 % on the Cornell frame together with the
+// smaller LDS tables below (three workgroups per CU instead of two).  The mirror / glass kernels need 109-135 registers and
+// get their third wave from the LDS budget alone; the Disney / metal / substrate kernels need 191-256 and stay at 2.
 #ifndef PTRS_SHADE_WAVES_MATTE
-#define PTRS_SHADE_WAVES_MATTE 2
+#define PTRS_SHADE_WAVES_MATTE 3
 #endif
 template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT == FEAT_SIMPLE) ? PTRS_SHADE_WAVES_MATTE : 2 }; }; // 2: never above 256 registers (one wave per SIMD otherwise)
 
@@ -499,10 +500,10 @@ template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT ==
 //   * the Sobol' tables of the dimensions this round can draw, in nibble form (16 words per index nibble and dimension):
 //     a sample is scramble ^ XOR of 8 (32-bit index) or 13 LDS words instead of 4 or 8 words gathered from L2.
 #ifndef PTRS_SH_SOB_WORDS
-#define PTRS_SH_SOB_WORDS 6144
+#define PTRS_SH_SOB_WORDS 3200
 #endif
 #ifndef PTRS_SH_TRI_V4
-#define PTRS_SH_TRI_V4 1024
+#define PTRS_SH_TRI_V4 512
 #endif
 enum : uint32_t { SH_SOB_WORDS = PTRS_SH_SOB_WORDS, SH_TRI_V4 = PTRS_SH_TRI_V4, SH_LIGHTS = 16, SH_LIGHT_V4 = sizeof(DLight) / 16, SH_TRI_REC_V4 = sizeof(DTriShade) / 16 };
 static_assert(sizeof(DLight) % 16 == 0 && sizeof(DTriShade) % 16 == 0, "records are staged as 16-byte vectors");
