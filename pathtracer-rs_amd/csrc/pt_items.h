@@ -73,7 +73,8 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
     f2 pf = mk2((float)c.px + u.x, (float)c.py + u.y);
     CamRay r = camera_ray(C, pf, R.inv_sqrt_spp);
     P.ray_o[pid] = mkv4(r.o, PT_INF);
-    P.ray_d[pid] = mkv4(r.d, 0.0f);
+    P.ray_d[pid] = mkv4(r.d, u2f(st.z)); // the path's state word (dimension counter | flags | bounces) travels with the ray direction: a vertex
+                                         // that continues rewrites ray_d anyway, and `st` keeps only what never changes (Sobol' index, scramble)
     P.beta[pid] = mkv4(splat3(1.0f), 1.0f);
     P.L[pid] = mkv4(splat3(0.0f), 0.0f);
     P.st[pid] = st;
@@ -89,14 +90,15 @@ PT_HD uint32_t st_pack(uint32_t dim, uint32_t flags, int32_t bounces) { return (
 // Returns the bucket (0..5) when the path goes on to shading, -1 when it ends here.
 template <int FEAT>
 PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P, uint32_t pid, const HitRec &h) {
-    const uint32_t stz = P.st[pid].z;
+    const v4 rdv = P.ray_d[pid];
+    const uint32_t stz = f2u(rdv.w);
     const int32_t prim = h.prim;
     const int32_t bounces = st_bounces(stz);
     if (bounces == 0 || (stz & ST_SPECULAR)) {
         if (prim >= 0) {
             if (h.flags & TRI_IS_LIGHT) {
                 const TriRegs T = load_tri_regs(sc.shade + prim);
-                f3 d = xyz(P.ray_d[pid]);
+                f3 d = xyz(rdv);
                 Surface s = tri_surface(T, prim, h.b0, h.b1, h.b2, -d);
                 f3 le = surface_le<FEAT>(sc, T, s, -d);
                 v4 Lv = P.L[pid];
@@ -104,7 +106,7 @@ PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P
                 P.L[pid] = mkv4(L, Lv.w);
             }
         } else if ((FEAT & FEAT_INFINITE) && sc.n_inf > 0) {
-            f3 d = xyz(P.ray_d[pid]);
+            f3 d = xyz(rdv);
             v4 Lv = P.L[pid];
             f3 L = xyz(Lv), beta = xyz(P.beta[pid]);
             for (uint32_t i = 0; i < sc.n_inf; ++i) L = L + beta * light_le<FEAT>(sc, sc.lights[sc.inf_lights[i]], d);
@@ -206,7 +208,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     // ---- memory round trip 1: the path's state (already requested by the caller) ------------------------------------
     const v4 rov = in.ro, rdv = in.rd;
     v4 bv = in.beta;
-    u4 stv = in.st;
+    u4 stv = in.st; stv.z = f2u(rdv.w); // the state word arrives in ray_d.w (generate_item)
     const u4 h = in.hit;
     const f3 ro = xyz(rov), rd = xyz(rdv);
     f3 beta = xyz(bv);
@@ -247,14 +249,14 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     // Everything this vertex writes is collected in registers and stored at the very end, behind X.before_stores(): the
     // gfx950 kernel waits there for the NEXT item's prefetched state (vmcnt counts loads and stores alike, so waiting
     // anywhere after a store would also wait for that store).
-    v4 w_sh_o, w_sh_d, w_mis_o, w_mis_d, w_nee0, w_nee1, w_ro, w_rd, w_beta; u4 w_nee2, w_st;
+    v4 w_sh_o, w_sh_d, w_mis_o, w_mis_d, w_nee0, w_nee1, w_ro, w_rd, w_beta; u4 w_nee2; uint32_t w_stz = stv.z;
     bool w_skip = false; // null-BSDF skip: only the ray origin and the state word change
-    w_sh_o = w_sh_d = w_mis_o = w_mis_d = w_nee0 = w_nee1 = w_ro = w_rd = w_beta = mkv4(splat3(0.0f), 0.0f); w_nee2.x = w_nee2.y = w_nee2.z = w_nee2.w = 0; w_st = stv;
+    w_sh_o = w_sh_d = w_mis_o = w_mis_d = w_nee0 = w_nee1 = w_ro = w_rd = w_beta = mkv4(splat3(0.0f), 0.0f); w_nee2.x = w_nee2.y = w_nee2.z = w_nee2.w = 0;
     BsdfT<MatLobes<MAT>::N> bsdf;
     if (!make_bsdf<MAT, FEAT>(sc, T.material, s, bsdf)) { // integrator.rs:434-439 (Q7)
         f3 o2 = spawn_origin(s.p, s.p_error, s.n, rd);
         w_ro = mkv4(o2, PT_INF);
-        w_st.z = st_pack(dim0, stv.z & ST_SPECULAR, bounces - 1);
+        w_stz = st_pack(dim0, stv.z & ST_SPECULAR, bounces - 1);
         w_skip = true;
     } else {
     PT_STAMP(3, f2u(bsdf.ss.x) + f2u(bsdf.ts.y) + f2u(s.p.x) + f2u(s.p_error.x))
@@ -316,7 +318,9 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             if (!out.mis) { // shadow ray only (always, for delta lights): resolve_item's arithmetic with its one unknown, the occlusion, left open
                 f3 ld = splat3(0.0f);
                 ld = ld + A;
-                w_nee0 = mkv4(beta * ((float)sc.n_lights * ld), 0.0f);
+                // (its three floats ride in the record's free slots -- sh_d.w, nee2.x, nee2.y -- so that a shadow-only record is three stores, not four)
+                const f3 c = beta * ((float)sc.n_lights * ld);
+                w_sh_d.w = c.x; w_nee2.x = f2u(c.y); w_nee2.y = f2u(c.z); w_nee2.z = 0u;
                 w_nee2.w |= NEE_PRE << 24;
             }
         }
@@ -352,9 +356,9 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             PT_STAMP(7, f2u(beta.x) + f2u(o2.x) + f2u(wi.x))
             bounces += 1;
             w_ro = mkv4(o2, PT_INF);
-            w_rd = mkv4(wi, 0.0f);
+            w_stz = st_pack(dim, spec ? ST_SPECULAR : 0u, bounces);
+            w_rd = mkv4(wi, u2f(w_stz));
             w_beta = mkv4(beta, eta_scale);
-            w_st.z = st_pack(dim, spec ? ST_SPECULAR : 0u, bounces);
             out.next = true;
         }
     }
@@ -364,9 +368,9 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     X.before_stores();
     if (out.shadow) { P.sh_o[pid] = w_sh_o; P.sh_d[pid] = w_sh_d; }
     if (out.mis) { P.mis_o[pid] = w_mis_o; P.mis_d[pid] = w_mis_d; }
-    if (out.nee) { P.nee0[pid] = w_nee0; if (out.mis) P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; }
-    if (w_skip) { P.ray_o[pid] = w_ro; P.st[pid] = w_st; out.next = true; }
-    else if (out.next) { P.ray_o[pid] = w_ro; P.ray_d[pid] = w_rd; P.beta[pid] = w_beta; P.st[pid] = w_st; }
+    if (out.nee) { if (out.mis) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; } P.nee2[pid] = w_nee2; } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1)
+    if (w_skip) { P.ray_o[pid] = w_ro; P.ray_d[pid] = mkv4(rd, u2f(w_stz)); out.next = true; }
+    else if (out.next) { P.ray_o[pid] = w_ro; P.ray_d[pid] = w_rd; P.beta[pid] = w_beta; }
     PT_STAMP(8, 0u)
     return out;
 }
@@ -380,8 +384,8 @@ template <int FEAT>
 PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid, bool occluded, const HitRec &mh) {
     const u4 n2 = P.nee2[pid];
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
-    if (fl & NEE_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (nee0.xyz = beta * nLights * ld)
-        if (!occluded) { const v4 c = P.nee0[pid], Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + xyz(c), Lv.w); }
+    if (fl & NEE_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, nee2.x, nee2.y)
+        if (!occluded) { const f3 c = mk3(P.sh_d[pid].w, u2f(n2.x), u2f(n2.y)); const v4 Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + c, Lv.w); }
         return;
     }
     const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
