@@ -81,6 +81,10 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
     P.pfilm[pid] = mkv4(mk3(pf.x, pf.y, 0.0f), 0.0f);
 }
 
+// t_max of every shadow ray: spawn_ray_to_it's 1 - 0.0001 (interaction.rs:50-60, Q13)
+#define PT_SHADOW_TMAX (1.0f - 0.0001f)
+struct alignas(8) PtU2 { uint32_t x, y; };
+
 PT_HD int32_t st_bounces(uint32_t z) { return (int32_t)(int16_t)(z >> ST_BOUNCE_SHIFT); }
 PT_HD uint32_t st_pack(uint32_t dim, uint32_t flags, int32_t bounces) { return (dim & ST_DIM_MASK) | flags | ((uint32_t)(uint16_t)(int16_t)bounces << ST_BOUNCE_SHIFT); }
 
@@ -282,7 +286,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
                 // VisibilityTester::unoccluded -> spawn_ray_to_it (interaction.rs:50-60, Q13)
                 f3 origin = offset_ray_origin(s.p, s.p_error, s.n, ls.p1 - s.p);
                 f3 target = offset_ray_origin(ls.p1, ls.p1_err, ls.p1_n, origin - ls.p1);
-                w_sh_o = mkv4(origin, 1.0f - 0.0001f);
+                w_sh_o = mkv4(origin, PT_SHADOW_TMAX);
                 w_sh_d = mkv4(target - origin, 0.0f);
                 A = delta ? f * ls.li / ls.pdf : f * ls.li * power_heuristic(ls.pdf, spdf) / ls.pdf;
                 out.shadow = true;
@@ -318,9 +322,11 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             if (!out.mis) { // shadow ray only (always, for delta lights): resolve_item's arithmetic with its one unknown, the occlusion, left open
                 f3 ld = splat3(0.0f);
                 ld = ld + A;
-                // (its three floats ride in the record's free slots -- sh_d.w, nee2.x, nee2.y -- so that a shadow-only record is three stores, not four)
+                // (its three floats ride in the record's free slots: sh_d.w, sh_o.w -- a shadow ray's t_max is the constant 1 - 1e-4, nobody reads
+                // it from there -- and nee2.z, so that a shadow-only record is 40 bytes in three stores instead of 64 in four: the shade stage's
+                // time follows the bytes it writes)
                 const f3 c = beta * ((float)sc.n_lights * ld);
-                w_sh_d.w = c.x; w_nee2.x = f2u(c.y); w_nee2.y = f2u(c.z); w_nee2.z = 0u;
+                w_sh_d.w = c.x; w_sh_o.w = c.y; w_nee2.z = f2u(c.z);
                 w_nee2.w |= NEE_PRE << 24;
             }
         }
@@ -368,7 +374,10 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     X.before_stores();
     if (out.shadow) { P.sh_o[pid] = w_sh_o; P.sh_d[pid] = w_sh_d; }
     if (out.mis) { P.mis_o[pid] = w_mis_o; P.mis_d[pid] = w_mis_d; }
-    if (out.nee) { if (out.mis) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; } P.nee2[pid] = w_nee2; } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1)
+    if (out.nee) {
+        if (out.mis) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; }
+        else { PtU2 zw; zw.x = w_nee2.z; zw.y = w_nee2.w; reinterpret_cast<PtU2 *>(P.nee2 + pid)[1] = zw; } // NEE_PRE: nothing in nee0 / nee1, 8 bytes of nee2
+    }
     if (w_skip) { P.ray_o[pid] = w_ro; P.ray_d[pid] = mkv4(rd, u2f(w_stz)); out.next = true; }
     else if (out.next) { P.ray_o[pid] = w_ro; P.ray_d[pid] = w_rd; P.beta[pid] = w_beta; }
     PT_STAMP(8, 0u)
@@ -384,8 +393,8 @@ template <int FEAT>
 PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid, bool occluded, const HitRec &mh) {
     const u4 n2 = P.nee2[pid];
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
-    if (fl & NEE_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, nee2.x, nee2.y)
-        if (!occluded) { const f3 c = mk3(P.sh_d[pid].w, u2f(n2.x), u2f(n2.y)); const v4 Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + c, Lv.w); }
+    if (fl & NEE_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, sh_o.w, nee2.z)
+        if (!occluded) { const f3 c = mk3(P.sh_d[pid].w, P.sh_o[pid].w, u2f(n2.z)); const v4 Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + c, Lv.w); }
         return;
     }
     const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
@@ -418,7 +427,7 @@ PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32
     if (fl & NEE_SHADOW) {
         const v4 o = P.sh_o[pid], d = P.sh_d[pid];
         HitRec h;
-        occluded = bvh_trace_g<QUAD, true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), o.w, stack, h, n_nodes, n_tris);
+        occluded = bvh_trace_g<QUAD, true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), PT_SHADOW_TMAX, stack, h, n_nodes, n_tris); // (sh_o.w may hold a NEE_PRE record's payload)
     }
     if (fl & NEE_MIS) {
         const v4 o = P.mis_o[pid];

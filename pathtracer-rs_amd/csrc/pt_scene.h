@@ -179,7 +179,7 @@ struct alignas(16) u4 { uint32_t x, y, z, w; };
 enum : uint32_t { ST_DIM_MASK = 0xfffu, ST_SPECULAR = 1u << 12, ST_HAS_DIFF = 1u << 13, ST_BOUNCE_SHIFT = 16 };
 // nee flags (stored in nee2.w as bits)
 enum : uint32_t { NEE_SHADOW = 1u, NEE_MIS = 2u,
-                  NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in (sh_d.w, nee2.x, nee2.y): the connect stage adds it when the ray is free
+                  NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in (sh_d.w, sh_o.w, nee2.z): the connect stage adds it when the ray is free
                   NEE_OCCLUDED = 0x80u }; // set by the split connect stage when the shadow ray was blocked
 
 struct DPaths {
@@ -192,8 +192,8 @@ struct DPaths {
     v4 *pfilm;  // p_film.xy, (unused) -- written by generate, read by the film kernel
     v4 *nee0;   // records with a MIS ray: A.rgb (light-sampling term, final if unoccluded), weight of the BSDF term
     v4 *nee1;   // f.rgb of the BSDF term (already times |wi.ns|), scattering pdf
-    u4 *nee2;   // beta at the vertex (rgb bits), light index | flags << 24; NEE_PRE records: contribution .y, .z bits in x, y
-    v4 *sh_o;   // shadow ray o.xyz, t_max
+    u4 *nee2;   // beta at the vertex (rgb bits), light index | flags << 24; NEE_PRE records write only z, w: contribution .z bits, flags
+    v4 *sh_o;   // shadow ray o.xyz (its t_max is the constant PT_SHADOW_TMAX); NEE_PRE records: contribution .y in w
     v4 *sh_d;   // shadow ray d.xyz; NEE_PRE records: contribution .x in w
     v4 *mis_o;  // MIS ray o.xyz
     v4 *mis_d;  // MIS ray d.xyz

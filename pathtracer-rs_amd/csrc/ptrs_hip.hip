@@ -406,8 +406,8 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
         if (batch && setup) {
             const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
             const v4 o = po[pid], d = pd[pid];
-            if (shadow_phase && (fl & NEE_PRE)) { const u4 n2 = P.nee2[pid]; pre_c.x = d.w; pre_c.y = u2f(n2.x); pre_c.z = u2f(n2.y); pre_l = P.L[pid]; } // shade_item's packing of a shadow-only record
-            RF_START(xyz(o), xyz(d), shadow_phase ? o.w : PT_INF)
+            if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = u2f(reinterpret_cast<const uint32_t *>(P.nee2 + pid)[2]); pre_l = P.L[pid]; } // shade_item's packing of a shadow-only record
+            RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
             stk.clear(); setup = false;
         }
         if (!__any(has)) break;
