@@ -78,7 +78,7 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
     P.beta[pid] = mkv4(splat3(1.0f), 1.0f);
     P.L[pid] = mkv4(splat3(0.0f), 0.0f);
     P.st[pid] = st;
-    P.pfilm[pid] = mkv4(mk3(pf.x, pf.y, 0.0f), 0.0f);
+    { f2a q; q.x = pf.x; q.y = pf.y; P.pfilm[pid] = q; }
 }
 
 // t_max of every shadow ray: spawn_ray_to_it's 1 - 0.0001 (interaction.rs:50-60, Q13)
@@ -246,7 +246,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     // Only the camera ray carries differentials (Q9) and only image-texture lookups read them
     // (texture.rs:185-191, 430-445), so without image textures they are dead values.
     if ((FEAT & FEAT_IMAGE) && (stv.z & ST_HAS_DIFF)) {
-        v4 pf = P.pfilm[pid];
+        const f2a pf = P.pfilm[pid];
         CamRay cr = camera_ray(C, mk2(pf.x, pf.y), R.inv_sqrt_spp);
         surface_differentials(s, ro, cr.rx_d, ro, cr.ry_d);
     }
@@ -482,7 +482,7 @@ PT_HD void film_item(const DParams &R, const DSampler &S, const DPaths &P, const
                 const int32_t sy = qy - S.min_y;
                 if (sy < R.row0 || sy >= R.row1) continue;
                 const uint32_t pid = k * npix + (uint32_t)(sy - R.row0) * (uint32_t)R.NX + (uint32_t)sx;
-                const v4 pf = P.pfilm[pid];
+                const f2a pf = P.pfilm[pid];
                 float w;
                 if (!film_weight(pf.x, pf.y, x, y, table, w)) continue;
                 const v4 Lv = P.L[pid];

@@ -174,6 +174,7 @@ struct DParams {
 
 struct alignas(16) v4 { float x, y, z, w; };
 struct alignas(16) u4 { uint32_t x, y, z, w; };
+struct alignas(8) f2a { float x, y; }; // an 8-byte element of a device array (one load / store)
 
 // path-state bits (u4.z of `st`)
 enum : uint32_t { ST_DIM_MASK = 0xfffu, ST_SPECULAR = 1u << 12, ST_HAS_DIFF = 1u << 13, ST_BOUNCE_SHIFT = 16 };
@@ -189,7 +190,7 @@ struct DPaths {
     v4 *L;      // L.rgb, (unused)
     u4 *st;     // what never changes along a path: sobol index lo, hi (stratified: pixel, sample), (unused), pixel scramble -- written once by k_generate
     u4 *hit;    // prim (int), b0, b1, b2 (float bits)
-    v4 *pfilm;  // p_film.xy, (unused) -- written by generate, read by the film kernel
+    f2a *pfilm; // p_film.xy (8 bytes per path) -- written by generate, read by the film kernel
     v4 *nee0;   // records with a MIS ray: A.rgb (light-sampling term, final if unoccluded), weight of the BSDF term
     v4 *nee1;   // f.rgb of the BSDF term (already times |wi.ns|), scattering pdf
     u4 *nee2;   // beta at the vertex (rgb bits), light index | flags << 24; NEE_PRE records write only z, w: contribution .z bits, flags

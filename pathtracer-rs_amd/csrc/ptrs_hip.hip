@@ -717,7 +717,7 @@ __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P,
             float pfx = -1.0e9f, pfy = -1.0e9f, lr = 0.0f, lg = 0.0f, lb = 0.0f; // far away: no pixel is in its footprint
             if (sx >= 0 && sx < R.NX && sy >= R.row0 && sy < R.row1) {
                 const uint32_t pid = k * npix + (uint32_t)(sy - R.row0) * (uint32_t)R.NX + (uint32_t)sx;
-                const v4 pf = P.pfilm[pid], Lv = P.L[pid];
+                const f2a pf = P.pfilm[pid]; const v4 Lv = P.L[pid];
                 pfx = pf.x; pfy = pf.y; lr = Lv.x; lg = Lv.y; lb = Lv.z;
             }
             s_pfx[e] = pfx; s_pfy[e] = pfy; s_lr[e] = lr; s_lg[e] = lg; s_lb[e] = lb;

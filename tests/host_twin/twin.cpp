@@ -71,7 +71,7 @@ struct HostBackend {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; feat = g_force_full ? FEAT_FULL : feat_;
         gaussian_filter_table(table);
         P.ray_o = alloc<v4>(cap); P.ray_d = alloc<v4>(cap); P.beta = alloc<v4>(cap); P.L = alloc<v4>(cap); P.st = alloc<u4>(cap); P.hit = alloc<u4>(cap);
-        P.pfilm = alloc<v4>(cap); P.nee0 = alloc<v4>(cap); P.nee1 = alloc<v4>(cap); P.nee2 = alloc<u4>(cap); P.sh_o = alloc<v4>(cap); P.sh_d = alloc<v4>(cap);
+        P.pfilm = alloc<f2a>(cap); P.nee0 = alloc<v4>(cap); P.nee1 = alloc<v4>(cap); P.nee2 = alloc<u4>(cap); P.sh_o = alloc<v4>(cap); P.sh_d = alloc<v4>(cap);
         P.mis_o = alloc<v4>(cap); P.mis_d = alloc<v4>(cap);
         Q.ext[0] = alloc<uint32_t>(cap); Q.ext[1] = alloc<uint32_t>(cap);
         for (int k = 0; k < Q_NUM_MAT; ++k) Q.mat[k] = alloc<uint32_t>(cap);
