@@ -185,7 +185,7 @@ PT_HD f3 lobe_f(const Lobe &l, f3 wo, f3 wi) {
             wh = normalize(wh);
             float c = dot(wi, wh);
             f3 schlick = l.t + pow5(1.0f - c) * (splat3(1.0f) - l.t);
-            f3 specular = (tr_d(l, wh) / (4.0f * fabs_(c) * max_(abs_cos(wi), abs_cos(wo)))) * schlick;
+            f3 specular = (tr_d(l, wh) / (4.0f * fabs_(c) * max_nz(abs_cos(wi), abs_cos(wo)))) * schlick;
             return diffuse + specular;
         }
         default: return splat3(0.0f);
@@ -249,11 +249,11 @@ PT_HD f3 lobe_sample_f(const Lobe &l, f3 wo, f3 &wi, f2 u, float &pdf, uint32_t 
         }
         default: { // LOBE_FRESNEL_BLEND
             if (u.x < 0.5f) {
-                u.x = min_(2.0f * u.x, PT_ONE_MINUS_EPS);
+                u.x = min_nz(2.0f * u.x, PT_ONE_MINUS_EPS);
                 wi = cosine_hemisphere(u);
                 if (wo.z < 0.0f) wi.z *= -1.0f;
             } else {
-                u.x = min_(2.0f * (u.x - 0.5f), PT_ONE_MINUS_EPS);
+                u.x = min_nz(2.0f * (u.x - 0.5f), PT_ONE_MINUS_EPS);
                 f3 wh = tr_sample_wh(l, wo, u);
                 wi = reflect_about(wo, wh);
                 if (!same_hemi(wo, wi)) return splat3(0.0f);

@@ -351,7 +351,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         if (R.rr_enable) {
             float mx = max_comp(beta * eta_scale);
             if (mx < R.rr_threshold && bounces > R.rr_start_depth) {
-                float q = max_(0.05f, 1.0f - mx);
+                float q = max_nz(0.05f, 1.0f - mx);
                 dim = D.after_rr; // get_1d
                 if (D.err_rr) { out.err_dim = true; alive = false; }
                 else if (u_tail[2] < q) alive = false;

@@ -7,11 +7,11 @@
 namespace pt {
 
 PT_HD float roughness_to_alpha(float roughness) { // microfacet.rs:118-127
-    roughness = max_(roughness, 1e-3f);
+    roughness = max_nz(roughness, 1e-3f);
     float x = pt_logf(roughness);
     return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
 }
-PT_HD void set_tr(Lobe &l, float ax, float ay, bool disney) { l.ax = max_(ax, 0.001f); l.ay = max_(ay, 0.001f); l.disney_g = disney; }
+PT_HD void set_tr(Lobe &l, float ax, float ay, bool disney) { l.ax = max_nz(ax, 0.001f); l.ay = max_nz(ay, 0.001f); l.disney_g = disney; }
 PT_HD Lobe blank_lobe(int kind) {
     Lobe l; l.kind = kind; l.r = splat3(0.0f); l.t = splat3(0.0f); l.eta_a = 1.0f; l.eta_b = 1.0f; l.fresnel = FR_NOOP;
     l.fa = splat3(0.0f); l.fb = splat3(0.0f); l.ax = 0.001f; l.ay = 0.001f; l.disney_g = false;
@@ -103,7 +103,7 @@ PT_HD bool make_bsdf(const DScene &sc, int32_t mat_id, Surface &s, BsdfT<MatLobe
         float lum = luminance(c);
         f3 c_tint = lum > 0.0f ? c / lum : splat3(1.0f);
         float aspect = 1.0f;
-        float ax = max_(0.001f, (rough * rough) / aspect), ay = max_(0.001f, (rough * rough) * aspect);
+        float ax = max_nz(0.001f, (rough * rough) / aspect), ay = max_nz(0.001f, (rough * rough) * aspect);
         float r0s = ((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f)); // schlick_r0_from_eta
         f3 spec0 = lerp3(r0s * lerp3(splat3(1.0f), c_tint, 0.0f), c, metallic);
         Lobe ld = blank_lobe(LOBE_DISNEY_DIFFUSE); ld.r = diffuse_weight * c;

@@ -41,7 +41,7 @@ PT_HD float sobol_sample(const DSampler &S, uint64_t index, uint32_t dim, uint32
         for (; index != 0; index >>= 1, ++mat)
             if (index & 1) v ^= *mat;
     }
-    return min_(PT_ONE_MINUS_EPS, (float)v * 0x1p-32f);
+    return min_nz(PT_ONE_MINUS_EPS, (float)v * 0x1p-32f);
 }
 
 // sample_dimension (sobol.rs:177-193): dimensions 0/1 are mapped to the pixel and clamped (Q1)
@@ -96,7 +96,7 @@ PT_HD void sobol_batch(const DSampler &S, uint64_t index, const uint32_t (&dim)[
         }
     }
 #pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = min_(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
+    for (int k = 0; k < N; ++k) out[k] = min_nz(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
 }
 
 // The dimensions one shading vertex draws, in the reference's order (integrator.rs:202-216, 453, 491): with next-event

@@ -35,7 +35,7 @@ PT_HD f3 tex_triangle(const DScene &sc, const DTexture &T, uint32_t level, f2 st
 
 PT_HD f3 tex_lookup_width(const DScene &sc, const DTexture &T, f2 st, float width) {
     float nl = (float)T.n_levels;
-    float level = nl - 1.0f + pt_log2f(max_(width, 1e-8f));
+    float level = nl - 1.0f + pt_log2f(max_nz(width, 1e-8f));
     if (level < 0.0f) return tex_triangle(sc, T, 0, st);
     if (level >= (float)(T.n_levels - 1)) return tex_triangle(sc, T, (uint32_t)T.n_levels - 1u, st);
     float il = floor_(level), delta = level - il;
@@ -56,7 +56,7 @@ PT_HD f3 tex_eval(const DScene &sc, int32_t id, f2 uv, float dudx, float dvdx, f
     }
     if (!(FEAT & FEAT_IMAGE)) return splat3(0.0f); // unreachable: the scene has no image texture
     float dx0 = T.su * dudx, dx1 = T.sv * dvdx, dy0 = T.su * dudy, dy1 = T.sv * dvdy;
-    float width = max_(max_(fabs_(dx0), fabs_(dx1)), max_(fabs_(dy0), fabs_(dy1)));
+    float width = max_nz(max_nz(fabs_(dx0), fabs_(dx1)), max_nz(fabs_(dy0), fabs_(dy1)));
     return tex_lookup_width(sc, T, st, width);
 }
 template <int FEAT>

@@ -61,14 +61,14 @@ PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2,
     float inv_det = 1.0f / det;
     float t = t_scaled * inv_det;
     // conservative t > delta_t test, shape.rs:163-185
-    float max_z = max_(max_(fabs_(p0t.z), fabs_(p1t.z)), fabs_(p2t.z));
+    float max_z = max_nz(max_nz(fabs_(p0t.z), fabs_(p1t.z)), fabs_(p2t.z)); // (absolute values: no +0 / -0 tie)
     float delta_z = gamma_err(3) * max_z;
-    float max_x = max_(max_(fabs_(p0t.x), fabs_(p1t.x)), fabs_(p2t.x));
-    float max_y = max_(max_(fabs_(p0t.y), fabs_(p1t.y)), fabs_(p2t.y));
+    float max_x = max_nz(max_nz(fabs_(p0t.x), fabs_(p1t.x)), fabs_(p2t.x));
+    float max_y = max_nz(max_nz(fabs_(p0t.y), fabs_(p1t.y)), fabs_(p2t.y));
     float delta_x = gamma_err(5) * (max_x + max_z);
     float delta_y = gamma_err(5) * (max_y + max_z);
     float delta_e = 2.0f * (gamma_err(2) * max_x * max_y + delta_y * max_x + delta_x * max_y);
-    float max_e = max_(max_(fabs_(e0), fabs_(e1)), fabs_(e2));
+    float max_e = max_nz(max_nz(fabs_(e0), fabs_(e1)), fabs_(e2));
     float delta_t = 3.0f * (gamma_err(3) * max_e * max_z + delta_e * max_z + delta_z * max_e) * fabs_(inv_det);
     if (t <= delta_t) return false;
     h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;

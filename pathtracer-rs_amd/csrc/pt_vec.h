@@ -41,6 +41,17 @@ PT_HD bool isnan_(float x) { return x != x; }
 // (written as three independent selects: the nested-ternary form compiles to exec-mask branches on gfx950)
 PT_HD float max_(float a, float b) { const float m = a > b ? a : b; const float r = b != b ? a : m; return a != a ? b : r; }
 PT_HD float min_(float a, float b) { const float m = a < b ? a : b; const float r = b != b ? a : m; return a != a ? b : r; }
+// The same where the two arguments cannot tie as +0 against -0 (absolute values, or one argument a non-zero constant): there the
+// hardware's v_max_f32 / v_min_f32 (IEEE maxNum / minNum: a NaN argument yields the other one) return the same bits as the
+// comparison form above in one instruction instead of six.  (With a +0 / -0 tie the comparison form returns its second argument,
+// the instruction +0 for max and -0 for min: callers that can see such a tie keep max_ / min_.)
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_HD float max_nz(float a, float b) { return __builtin_fmaxf(a, b); }
+PT_HD float min_nz(float a, float b) { return __builtin_fminf(a, b); }
+#else
+PT_HD float max_nz(float a, float b) { return max_(a, b); }
+PT_HD float min_nz(float a, float b) { return min_(a, b); }
+#endif
 PT_HD float clamp_(float x, float lo, float hi) { if (x < lo) x = lo; if (x > hi) x = hi; return x; }
 
 struct f2 { float x, y; };

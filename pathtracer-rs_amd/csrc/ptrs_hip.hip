@@ -547,7 +547,7 @@ struct ShadeCtxLds {
 #pragma unroll
             for (int k = 0; k < N; ++k) v[k] = scramble ^ t0[k * ST] ^ t1[k * ST] ^ t2[k * ST] ^ t3[k * ST] ^ t4[k * ST] ^ t5[k * ST] ^ t6[k * ST] ^ t7[k * ST];
 #pragma unroll
-            for (int k = 0; k < N; ++k) out[k] = min_(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
+            for (int k = 0; k < N; ++k) out[k] = min_nz(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
             return;
         }
         const uint32_t stride = sob_stride(cfg.sob_nib);
@@ -565,7 +565,7 @@ struct ShadeCtxLds {
             }
         }
 #pragma unroll
-        for (int k = 0; k < N; ++k) out[k] = min_(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
+        for (int k = 0; k < N; ++k) out[k] = min_nz(PT_ONE_MINUS_EPS, (float)v[k] * 0x1p-32f);
     }
 };
 
