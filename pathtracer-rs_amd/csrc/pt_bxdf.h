@@ -17,7 +17,7 @@ enum : int { FR_NOOP = 0, FR_CONDUCTOR = 1, FR_DISNEY = 2 };
 
 PT_HD float cos2_theta(f3 w) { return w.z * w.z; }
 PT_HD float abs_cos(f3 w) { return fabs_(w.z); }
-PT_HD float sin2_theta(f3 w) { return max_(0.0f, 1.0f - cos2_theta(w)); }
+PT_HD float sin2_theta(f3 w) { return max0_(1.0f - cos2_theta(w)); }
 PT_HD float sin_theta(f3 w) { return sqrt_(sin2_theta(w)); }
 PT_HD float tan2_theta(f3 w) { return sin2_theta(w) / cos2_theta(w); }
 PT_HD float tan_theta(f3 w) { return sin_theta(w) / w.z; }
@@ -27,7 +27,7 @@ PT_HD bool same_hemi(f3 a, f3 b) { return a.z * b.z > 0.0f; }
 PT_HD f3 reflect_about(f3 wo, f3 n) { return -wo + 2.0f * dot(wo, n) * n; }
 PT_HD bool refract_dir(f3 wi, f3 n, float eta, f3 &wt) {
     float ci = dot(n, wi);
-    float s2i = max_(0.0f, 1.0f - ci * ci);
+    float s2i = max0_(1.0f - ci * ci);
     float s2t = eta * eta * s2i;
     if (s2t > 1.0f) return false;
     float ct = sqrt_(1.0f - s2t);
@@ -45,15 +45,15 @@ PT_HD f2 concentric_disk(f2 u) {
 }
 PT_HD f3 cosine_hemisphere(f2 u) {
     f2 d = concentric_disk(u);
-    return mk3(d.x, d.y, sqrt_(max_(0.0f, 1.0f - d.x * d.x - d.y * d.y)));
+    return mk3(d.x, d.y, sqrt_(max0_(1.0f - d.x * d.x - d.y * d.y)));
 }
 PT_HD float fr_dielectric(float ci, float eta_i, float eta_t) {
     ci = clamp_(ci, -1.0f, 1.0f);
     if (!(ci > 0.0f)) { float t = eta_i; eta_i = eta_t; eta_t = t; ci = fabs_(ci); }
-    float si = sqrt_(max_(0.0f, 1.0f - ci * ci));
+    float si = sqrt_(max0_(1.0f - ci * ci));
     float st = eta_i / eta_t * si;
     if (st >= 1.0f) return 1.0f;
-    float ct = sqrt_(max_(0.0f, 1.0f - st * st));
+    float ct = sqrt_(max0_(1.0f - st * st));
     float r_parl = ((eta_t * ci) - (eta_i * ct)) / ((eta_t * ci) + (eta_i * ct));
     float r_perp = ((eta_i * ci) - (eta_t * ct)) / ((eta_i * ci) + (eta_t * ct));
     return (r_parl * r_parl + r_perp * r_perp) / 2.0f;
@@ -131,7 +131,7 @@ PT_HD void tr_sample11(float ct, float u1, float u2, float &sx, float &sy) {
         sx = r * cs; sy = r * sn;
         return;
     }
-    float st = sqrt_(max_(0.0f, 1.0f - ct * ct));
+    float st = sqrt_(max0_(1.0f - ct * ct));
     float tt = st / ct;
     float alpha = 1.0f / tt;
     float g1 = 2.0f / (1.0f + sqrt_(1.0f + 1.0f / (alpha * alpha)));
@@ -139,7 +139,7 @@ PT_HD void tr_sample11(float ct, float u1, float u2, float &sx, float &sy) {
     float tmp = 1.0f / (a * a - 1.0f);
     if (tmp > 1e10f) tmp = 1e10f;
     float b = tt;
-    float dd = sqrt_(max_(0.0f, b * b * tmp * tmp - (a * a - b * b) * tmp));
+    float dd = sqrt_(max0_(b * b * tmp * tmp - (a * a - b * b) * tmp));
     float s1 = b * tmp - dd, s2 = b * tmp + dd;
     sx = (a < 0.0f || s2 > (1.0f / tt)) ? s1 : s2;
     float s;

@@ -264,6 +264,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         w_skip = true;
     } else {
     PT_STAMP(3, f2u(bsdf.ss.x) + f2u(bsdf.ts.y) + f2u(s.p.x) + f2u(s.p_error.x))
+    const SpawnPair sp = spawn_pair(s.p, s.p_error, s.n); // every ray and pdf query of this vertex leaves from one of two offset points
     // ---- direct lighting: uniform_sample_one_light + estimate_direct up to the scene queries ----
     const uint32_t NS = BSDF_ALL & ~BSDF_SPECULAR;
     const bool do_nee = bsdf_num(bsdf, NS) > 0 && sc.n_lights > 0;
@@ -274,7 +275,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         const f2 u_light = mk2(u_nee[0], u_nee[1]), u_scat = mk2(u_nee[2], u_nee[3]);
         const bool delta = light_is_delta(Lt);
         LightSample ls;
-        light_sample_li<FEAT>(sc, Lt, s.p, s.p_error, s.n, u_light, ls);
+        light_sample_li<FEAT>(sc, Lt, s.p, sp, u_light, ls);
         PT_STAMP(4, f2u(ls.pdf) + f2u(ls.wi.x) + f2u(ls.li.x) + f2u(ls.p1.x))
         f3 A = splat3(0.0f);
         float spdf = 0.0f;
@@ -284,7 +285,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             spdf = bsdf_pdf(bsdf, wo, wi, NS);
             if (!is_black(f)) {
                 // VisibilityTester::unoccluded -> spawn_ray_to_it (interaction.rs:50-60, Q13)
-                f3 origin = offset_ray_origin(s.p, s.p_error, s.n, ls.p1 - s.p);
+                f3 origin = spawn_from(sp, ls.p1 - s.p);
                 f3 target = offset_ray_origin(ls.p1, ls.p1_err, ls.p1_n, origin - ls.p1);
                 w_sh_o = mkv4(origin, PT_SHADOW_TMAX);
                 w_sh_d = mkv4(target - origin, 0.0f);
@@ -301,12 +302,12 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             if (!is_black(fB) && spdf > 0.0f) {
                 bool ok = true;
                 if (!(sampled & BSDF_SPECULAR)) {
-                    float lpdf = light_pdf_li<FEAT>(sc, Lt, s.p, s.p_error, s.n, wi);
+                    float lpdf = light_pdf_li<FEAT>(sc, Lt, s.p, sp, wi);
                     if (lpdf == 0.0f) ok = false; // `return ld` (Q11)
                     else wB = power_heuristic(spdf, lpdf);
                 }
                 if (ok) {
-                    w_mis_o = mkv4(spawn_origin(s.p, s.p_error, s.n, wi), PT_INF);
+                    w_mis_o = mkv4(spawn_from(sp, wi), PT_INF);
                     w_mis_d = mkv4(wi, 0.0f);
                     out.mis = true;
                 }
@@ -347,7 +348,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             float eta = bsdf.eta;
             eta_scale *= dot(wo, s.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
         }
-        f3 o2 = spawn_origin(s.p, s.p_error, s.n, wi);
+        f3 o2 = spawn_from(sp, wi);
         if (R.rr_enable) {
             float mx = max_comp(beta * eta_scale);
             if (mx < R.rr_threshold && bounces > R.rr_start_depth) {

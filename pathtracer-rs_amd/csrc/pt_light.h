@@ -62,8 +62,8 @@ PT_HD void tri_point_normal(const TriRegs &T, float b0, float b1, float b2, f3 &
 
 // Triangle::pdf_at_point (shape.rs:62-72): a single-triangle intersection from the offset origin
 template <int FEAT>
-PT_HD float tri_pdf_at_point(const DScene &sc, const TriRegs &T, float area, f3 ref_p, f3 ref_err, f3 ref_n, f3 wi, const float *n_fixed = nullptr) {
-    f3 o = spawn_origin(ref_p, ref_err, ref_n, wi);
+PT_HD float tri_pdf_at_point(const DScene &sc, const TriRegs &T, float area, f3 ref_p, const SpawnPair &ref_sp, f3 wi, const float *n_fixed = nullptr) {
+    f3 o = spawn_from(ref_sp, wi); // = spawn_origin(ref_p, ref_err, ref_n, wi)
     TriHit h;
     if (!tri_test(o, wi, PT_INF, T.p0, T.p1, T.p2, h)) return 0.0f;
     if (T.flags & TRI_DEGENERATE) return 0.0f;
@@ -93,7 +93,7 @@ PT_HD float dist1d_sample(const float *func, const float *cdf, float func_int, u
 // Light::sample_li.  Returns false when the reference leaves the visibility tester unset
 // (InfiniteAreaLight with map_pdf == 0, light.rs:411-413) -- the reference would panic there.
 template <int FEAT>
-PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f2 u, LightSample &o) {
+PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const SpawnPair &ref_sp, f2 u, LightSample &o) {
     o.p1_err = splat3(0.0f); o.p1_n = splat3(0.0f);
     if (L.kind == 0) { // point
         f3 pl = ld3(L.v);
@@ -112,7 +112,7 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
         f3 p, n, perr; f2 uv;
         tri_sample(T, u, p, n, perr, uv, L.n_ok ? L.n_sample : nullptr);
         o.wi = normalize(p - ref_p);
-        o.pdf = tri_pdf_at_point<FEAT>(sc, T, L.area, ref_p, ref_err, ref_n, o.wi, L.n_ok ? L.n_point : nullptr);
+        o.pdf = tri_pdf_at_point<FEAT>(sc, T, L.area, ref_p, ref_sp, o.wi, L.n_ok ? L.n_point : nullptr);
         o.p1 = p; o.p1_err = perr; o.p1_n = n;
         f3 w = -o.wi;
         o.li = dot(n, w) > 0.0f ? (L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f)) : splat3(0.0f);
@@ -137,8 +137,8 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_e
 }
 
 template <int FEAT>
-PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, f3 ref_err, f3 ref_n, f3 w) {
-    if (L.kind == 2) return tri_pdf_at_point<FEAT>(sc, load_tri_regs(&L.T), L.area, ref_p, ref_err, ref_n, w, L.n_ok ? L.n_point : nullptr);
+PT_HD float light_pdf_li(const DScene &sc, const DLight &L, f3 ref_p, const SpawnPair &ref_sp, f3 w) {
+    if (L.kind == 2) return tri_pdf_at_point<FEAT>(sc, load_tri_regs(&L.T), L.area, ref_p, ref_sp, w, L.n_ok ? L.n_point : nullptr);
     if ((FEAT & FEAT_INFINITE) && L.kind == 3) {
         f3 wi = xform_vec(L.w2l, w);
         float theta = spherical_theta(wi), phi = spherical_phi(wi);

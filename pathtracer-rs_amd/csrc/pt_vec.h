@@ -41,6 +41,8 @@ PT_HD bool isnan_(float x) { return x != x; }
 // (written as three independent selects: the nested-ternary form compiles to exec-mask branches on gfx950)
 PT_HD float max_(float a, float b) { const float m = a > b ? a : b; const float r = b != b ? a : m; return a != a ? b : r; }
 PT_HD float min_(float a, float b) { const float m = a < b ? a : b; const float r = b != b ? a : m; return a != a ? b : r; }
+// max_(0.0f, x) in two instructions: x unless it is negative or a NaN (a -0 comes back as -0, as from the comparison form)
+PT_HD float max0_(float x) { return x >= 0.0f ? x : 0.0f; }
 // The same where the two arguments cannot tie as +0 against -0 (absolute values, or one argument a non-zero constant): there the
 // hardware's v_max_f32 / v_min_f32 (IEEE maxNum / minNum: a NaN argument yields the other one) return the same bits as the
 // comparison form above in one instruction instead of six.  (With a +0 / -0 tie the comparison form returns its second argument,
@@ -114,6 +116,19 @@ PT_HD f3 offset_ray_origin(f3 p, f3 p_error, f3 n, f3 w) {
     f3 po = p + off;
     return mk3(nudge(po.x, off.x), nudge(po.y, off.y), nudge(po.z, off.z));
 }
+// A shading vertex offsets its point up to six times (light-sample pdf, shadow ray, BSDF-sample pdf, MIS ray, continuation, ...)
+// with the same p, p_error and n: the direction enters only through the sign of dot(w, n).  Both outcomes once, a select per use.
+struct SpawnPair { f3 n, plus, minus; };
+PT_HD SpawnPair spawn_pair(f3 p, f3 p_error, f3 n) {
+    SpawnPair sp; sp.n = n;
+    const float d = dot(abs3(n), p_error);
+    const f3 off = d * n, noff = -off;
+    const f3 pp = p + off, pm = p + noff;
+    sp.plus = mk3(nudge(pp.x, off.x), nudge(pp.y, off.y), nudge(pp.z, off.z));
+    sp.minus = mk3(nudge(pm.x, noff.x), nudge(pm.y, noff.y), nudge(pm.z, noff.z));
+    return sp;
+}
+PT_HD f3 spawn_from(const SpawnPair &sp, f3 w) { return dot(w, sp.n) < 0.0f ? sp.minus : sp.plus; } // == offset_ray_origin(p, p_error, n, w)
 PT_HD float power_heuristic(float f_pdf, float g_pdf) { // nf = ng = 1 (1.0 * pdf is exact)
     float f = 1.0f * f_pdf, g = 1.0f * g_pdf;
     return (f * f) / (f * f + g * g);
