@@ -607,7 +607,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
     const uint32_t wv = threadIdx.x >> 6;
     auto dma = [&](uint32_t p) {
         typedef __attribute__((address_space(1))) const void gptr; typedef __attribute__((address_space(3))) void lptr;
-        __builtin_amdgcn_global_load_lds((gptr *)(P.ray_o + p), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0);
+        if (FEAT & FEAT_IMAGE) __builtin_amdgcn_global_load_lds((gptr *)(P.ray_o + p), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0); // (the ray's origin is only read for the camera ray's differentials, which only image-texture lookups use)
         __builtin_amdgcn_global_load_lds((gptr *)(P.ray_d + p), (lptr *)(lds_pf + (1u * 4u + wv) * 64u), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr *)(P.beta + p), (lptr *)(lds_pf + (2u * 4u + wv) * 64u), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr *)(P.st + p), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
@@ -621,7 +621,8 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         PathIn in;
         {
             lds_v4 *q = (lds_v4 *)lds_pf + threadIdx.x;
-            in.ro = X.ld(q); in.rd = X.ld(q + BLOCK); in.beta = X.ld(q + 2 * BLOCK);
+            if (FEAT & FEAT_IMAGE) in.ro = X.ld(q); else in.ro = mkv4(splat3(0.0f), 0.0f);
+            in.rd = X.ld(q + BLOCK); in.beta = X.ld(q + 2 * BLOCK);
             const v4 a = X.ld(q + 3 * BLOCK), c = X.ld(q + 4 * BLOCK);
             in.st.x = f2u(a.x); in.st.y = f2u(a.y); in.st.z = f2u(a.z); in.st.w = f2u(a.w);
             in.hit.x = f2u(c.x); in.hit.y = f2u(c.y); in.hit.z = f2u(c.z); in.hit.w = f2u(c.w);
