@@ -219,8 +219,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     float eta_scale = bv.w;
     const int32_t prim = hit_prim(h.x);
     int32_t bounces = st_bounces(stv.z);
-    const uint64_t index = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
-    const uint32_t dim0 = stv.z & ST_DIM_MASK, scramble = stv.w;
+    const uint32_t dim0 = stv.z & ST_DIM_MASK;
     PT_STAMP(0, h.x + stv.z + f2u(rov.x) + f2u(rdv.x) + f2u(bv.x))
     // ---- round trip 2: the triangle's shading record and ALL Sobol' table entries this vertex can need -----------
     // Whether the vertex does next-event estimation is a property of the material kind, except for a Substrate without
