@@ -701,7 +701,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_counts(const uint32_t *__restr
 // fetched 102 GB per frame).  Same sums, same order as film_item.
 __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P, const float *__restrict__ table, v4 *film, int32_t y0, int32_t y1, int32_t tiles_x) {
     __shared__ float tab[256];
-    __shared__ float s_pfx[400], s_pfy[400], s_lr[400], s_lg[400], s_lb[400];
+    __shared__ v4 s_a[400]; __shared__ float s_lb[400]; // p_film.xy, L.rg | L.b: one 16-byte and one 4-byte LDS read per candidate
     tab[threadIdx.x] = table[threadIdx.x];
     const int32_t tx0 = (int32_t)(blockIdx.x % (uint32_t)tiles_x) * 16, ty0 = y0 + (int32_t)(blockIdx.x / (uint32_t)tiles_x) * 16;
     const int32_t lx = (int32_t)(threadIdx.x & 15u), ly = (int32_t)(threadIdx.x >> 4);
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P,
                 const f2a pf = P.pfilm[pid]; const v4 Lv = P.L[pid];
                 pfx = pf.x; pfy = pf.y; lr = Lv.x; lg = Lv.y; lb = Lv.z;
             }
-            s_pfx[e] = pfx; s_pfy[e] = pfy; s_lr[e] = lr; s_lg[e] = lg; s_lb[e] = lb;
+            v4 a; a.x = pfx; a.y = pfy; a.z = lr; a.w = lg; s_a[e] = a; s_lb[e] = lb;
         }
         __syncthreads();
         if (live) {
@@ -729,8 +729,9 @@ __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P,
                 for (int32_t dy = 0; dy < 5; ++dy) {
                     const int32_t e = (ly + dy) * 20 + (lx + dx);
                     float w;
-                    if (!film_weight(s_pfx[e], s_pfy[e], x, y, tab, w)) continue;
-                    acc.x += s_lr[e] * w; acc.y += s_lg[e] * w; acc.z += s_lb[e] * w; acc.w += w;
+                    const v4 a = s_a[e];
+                    if (!film_weight(a.x, a.y, x, y, tab, w)) continue;
+                    acc.x += a.z * w; acc.y += a.w * w; acc.z += s_lb[e] * w; acc.w += w;
                 }
         }
     }
