@@ -198,7 +198,7 @@ struct ShadeCtx {
     PT_MEM void before_stores() const {}
 };
 
-struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; }; // err_dim: a Sobol dimension >= 1024 was drawn (the reference panics, sobol.rs:177-183)
+struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; PT_MEM uint32_t nee_entry(uint32_t pid) const { return pid | (mis ? 0u : (uint32_t)NEE_Q_PRE); } }; // err_dim: a Sobol dimension >= 1024 was drawn (the reference panics, sobol.rs:177-183)
 
 // What a shading vertex reads of its path: five 16-byte vectors out of HBM (nothing else of a path is cache-resident: a
 // pass holds tens of GB of path state).  The gfx950 shade kernel fetches the NEXT item's PathIn while it shades the
@@ -252,7 +252,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     // Everything this vertex writes is collected in registers and stored at the very end, behind X.before_stores(): the
     // gfx950 kernel waits there for the NEXT item's prefetched state (vmcnt counts loads and stores alike, so waiting
     // anywhere after a store would also wait for that store).
-    v4 w_sh_o, w_sh_d, w_mis_o, w_mis_d, w_nee0, w_nee1, w_ro, w_rd, w_beta; u4 w_nee2; uint32_t w_stz = stv.z;
+    v4 w_sh_o, w_sh_d, w_mis_o, w_mis_d, w_nee0, w_nee1, w_ro, w_rd, w_beta; u4 w_nee2; uint32_t w_stz = stv.z; float w_cz = 0.0f; bool w_pre = false;
     bool w_skip = false; // null-BSDF skip: only the ray origin and the state word change
     w_sh_o = w_sh_d = w_mis_o = w_mis_d = w_nee0 = w_nee1 = w_ro = w_rd = w_beta = mkv4(splat3(0.0f), 0.0f); w_nee2.x = w_nee2.y = w_nee2.z = w_nee2.w = 0;
     BsdfT<MatLobes<MAT>::N> bsdf;
@@ -322,12 +322,12 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             if (!out.mis) { // shadow ray only (always, for delta lights): resolve_item's arithmetic with its one unknown, the occlusion, left open
                 f3 ld = splat3(0.0f);
                 ld = ld + A;
-                // (its three floats ride in the record's free slots: sh_d.w, sh_o.w -- a shadow ray's t_max is the constant 1 - 1e-4, nobody reads
-                // it from there -- and nee2.z, so that a shadow-only record is 40 bytes in three stores instead of 64 in four: the shade stage's
-                // time follows the bytes it writes)
+                // (its three floats ride in free slots: sh_d.w, sh_o.w -- a shadow ray's t_max is the constant 1 - 1e-4, nobody reads it from
+                // there -- and ray_o.w, the slot of the extension ray's constant t_max, which a continuing vertex stores anyway; the record's kind
+                // travels in the queue entry (NEE_Q_PRE).  A shadow-only record is 32 bytes in two stores instead of 64 in four: the shade
+                // stage's time follows the bytes it writes.)
                 const f3 c = beta * ((float)sc.n_lights * ld);
-                w_sh_d.w = c.x; w_sh_o.w = c.y; w_nee2.z = f2u(c.z);
-                w_nee2.w |= NEE_PRE << 24;
+                w_sh_d.w = c.x; w_sh_o.w = c.y; w_cz = c.z; w_pre = true;
             }
         }
     }
@@ -368,16 +368,14 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             out.next = true;
         }
     }
-    if (out.err_dim) { out.nee = false; out.shadow = false; out.mis = false; out.next = false; }
+    if (out.err_dim) { out.nee = false; out.shadow = false; out.mis = false; out.next = false; w_pre = false; }
     }
     // ---- the vertex's stores ------------------------------------------------------------------------------------------
     X.before_stores();
     if (out.shadow) { P.sh_o[pid] = w_sh_o; P.sh_d[pid] = w_sh_d; }
     if (out.mis) { P.mis_o[pid] = w_mis_o; P.mis_d[pid] = w_mis_d; }
-    if (out.nee) {
-        if (out.mis) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; }
-        else { PtU2 zw; zw.x = w_nee2.z; zw.y = w_nee2.w; reinterpret_cast<PtU2 *>(P.nee2 + pid)[1] = zw; } // NEE_PRE: nothing in nee0 / nee1, 8 bytes of nee2
-    }
+    if (out.mis) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1 / nee2)
+    if (w_pre) { if (out.next) w_ro.w = w_cz; else reinterpret_cast<float *>(P.ray_o + pid)[3] = w_cz; }
     if (w_skip) { P.ray_o[pid] = w_ro; P.ray_d[pid] = mkv4(rd, u2f(w_stz)); out.next = true; }
     else if (out.next) { P.ray_o[pid] = w_ro; P.ray_d[pid] = w_rd; P.beta[pid] = w_beta; }
     PT_STAMP(8, 0u)
@@ -390,13 +388,14 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 // The part of estimate_direct after its two scene queries: `occluded` is the shadow ray's answer, `mh` the MIS ray's
 // closest hit (prim < 0: it escaped).
 template <int FEAT>
-PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid, bool occluded, const HitRec &mh) {
-    const u4 n2 = P.nee2[pid];
-    const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
-    if (fl & NEE_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, sh_o.w, nee2.z)
-        if (!occluded) { const f3 c = mk3(P.sh_d[pid].w, P.sh_o[pid].w, u2f(n2.z)); const v4 Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + c, Lv.w); }
+PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, bool occluded, const HitRec &mh) {
+    const uint32_t pid = entry & ~(uint32_t)NEE_Q_PRE;
+    if (entry & NEE_Q_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, sh_o.w, ray_o.w)
+        if (!occluded) { const f3 c = mk3(P.sh_d[pid].w, P.sh_o[pid].w, P.ray_o[pid].w); const v4 Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + c, Lv.w); }
         return;
     }
+    const u4 n2 = P.nee2[pid];
+    const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
     const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
     f3 ld = splat3(0.0f);
     if ((fl & NEE_SHADOW) && !occluded) ld = ld + xyz(n0);
@@ -420,8 +419,9 @@ PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t pid, bool oc
 }
 
 template <int FEAT, bool QUAD, class Stack, class Geom>
-PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t pid, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
-    const uint32_t fl = P.nee2[pid].w >> 24;
+PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t entry, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
+    const uint32_t pid = entry & ~(uint32_t)NEE_Q_PRE;
+    const uint32_t fl = (entry & NEE_Q_PRE) ? (uint32_t)(NEE_SHADOW | NEE_PRE) : P.nee2[pid].w >> 24;
     bool occluded = false;
     HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
     if (fl & NEE_SHADOW) {
@@ -433,7 +433,7 @@ PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32
         const v4 o = P.mis_o[pid];
         if (!bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(P.mis_d[pid]), PT_INF, stack, mh, n_nodes, n_tris)) mh.prim = -1;
     }
-    resolve_item<FEAT>(sc, P, pid, occluded, mh);
+    resolve_item<FEAT>(sc, P, entry, occluded, mh);
 }
 
 // run-time material dispatch (host twin; the HIP back end launches one specialised kernel per bucket)

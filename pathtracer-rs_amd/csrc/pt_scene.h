@@ -178,13 +178,16 @@ struct alignas(8) f2a { float x, y; }; // an 8-byte element of a device array (o
 
 // path-state bits (u4.z of `st`)
 enum : uint32_t { ST_DIM_MASK = 0xfffu, ST_SPECULAR = 1u << 12, ST_HAS_DIFF = 1u << 13, ST_BOUNCE_SHIFT = 16 };
+// An entry of the NEE queue: the path slot, and in bit 31 whether the record is shadow-only (NEE_PRE).  Such a record needs no flags word:
+// its kind is known from the queue, and the connect stage reads nothing of nee0 / nee1 / nee2 for it.
+enum : uint32_t { NEE_Q_PRE = 0x80000000u };
 // nee flags (stored in nee2.w as bits)
 enum : uint32_t { NEE_SHADOW = 1u, NEE_MIS = 2u,
-                  NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in (sh_d.w, sh_o.w, nee2.z): the connect stage adds it when the ray is free
+                  NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in (sh_d.w, sh_o.w, ray_o.w): the connect stage adds it when the ray is free
                   NEE_OCCLUDED = 0x80u }; // set by the split connect stage when the shadow ray was blocked
 
 struct DPaths {
-    v4 *ray_o;  // o.xyz, t_max
+    v4 *ray_o;  // o.xyz (an extension ray's t_max is +inf; nobody reads it from here); w: contribution .z of a pending NEE_PRE record
     v4 *ray_d;  // d.xyz, the path's state word (dimension counter | flags | bounces): rewritten with the direction by every vertex that continues
     v4 *beta;   // beta.rgb, eta_scale
     v4 *L;      // L.rgb, (unused)
@@ -193,7 +196,7 @@ struct DPaths {
     f2a *pfilm; // p_film.xy (8 bytes per path) -- written by generate, read by the film kernel
     v4 *nee0;   // records with a MIS ray: A.rgb (light-sampling term, final if unoccluded), weight of the BSDF term
     v4 *nee1;   // f.rgb of the BSDF term (already times |wi.ns|), scattering pdf
-    u4 *nee2;   // beta at the vertex (rgb bits), light index | flags << 24; NEE_PRE records write only z, w: contribution .z bits, flags
+    u4 *nee2;   // records with a MIS ray: beta at the vertex (rgb bits), light index | flags << 24
     v4 *sh_o;   // shadow ray o.xyz (its t_max is the constant PT_SHADOW_TMAX); NEE_PRE records: contribution .y in w
     v4 *sh_d;   // shadow ray d.xyz; NEE_PRE records: contribution .x in w
     v4 *mis_o;  // MIS ray o.xyz

@@ -203,8 +203,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpi
         const v4 o = P.ray_o[pid], d = P.ray_d[pid];
         LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
         HitRec h;
-        if (GEOM > 0) bvh_trace_g<false, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt); // pair nodes in LDS
-        else bvh_trace_g<true, false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);           // quad nodes through L1/L2
+        if (GEOM > 0) bvh_trace_g<false, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), PT_INF, stk, h, nn, nt); // pair nodes in LDS (ray_o.w is not the ray's t_max: pt_scene.h)
+        else bvh_trace_g<true, false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), PT_INF, stk, h, nn, nt);           // quad nodes through L1/L2
         u4 r; r.x = hit_pack(h.prim, h.flags); r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
         P.hit[pid] = r;
         const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
                 if (i < n) {
                     pid = queue[i];
                     const v4 ov = P.ray_o[pid], dv = P.ray_d[pid];
-                    RF_START(xyz(ov), xyz(dv), ov.w)
+                    RF_START(xyz(ov), xyz(dv), PT_INF)
                     stk.clear(); has = true;
                 } else dry = true;
             }
@@ -396,8 +396,9 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             if (!has) {
                 const uint32_t i = rf_take(&cursor, idle);
                 if (i < n) {
-                    pid = queue[i];
-                    fl = reinterpret_cast<const uint32_t *>(P.nee2 + pid)[3] >> 24;
+                    const uint32_t entry = queue[i]; // path slot | NEE_Q_PRE
+                    pid = entry & ~(uint32_t)NEE_Q_PRE;
+                    fl = (entry & NEE_Q_PRE) ? (uint32_t)(NEE_SHADOW | NEE_PRE) : reinterpret_cast<const uint32_t *>(P.nee2 + pid)[3] >> 24;
                     if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
                 } else dry = true;
             }
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
         if (batch && setup) {
             const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
             const v4 o = po[pid], d = pd[pid];
-            if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = u2f(reinterpret_cast<const uint32_t *>(P.nee2 + pid)[2]); pre_l = P.L[pid]; } // shade_item's packing of a shadow-only record
+            if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = reinterpret_cast<const float *>(P.ray_o + pid)[3]; pre_l = P.L[pid]; } // shade_item's packing of a shadow-only record
             RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
             stk.clear(); setup = false;
         }
@@ -433,8 +434,8 @@ __device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const 
     if (*seg_count(Q, it, Q_MIS, G, b) == 0) return; // every record of the segment was shadow-only: k_connect_rf has resolved them
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
         const uint32_t pid = queue[i];
+        if (pid & NEE_Q_PRE) continue; // shadow-only: resolved when its ray retired
         const uint32_t fl = P.nee2[pid].w >> 24;
-        if (fl & NEE_PRE) continue;
         HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
         if (fl & NEE_MIS) { const u4 v = P.hit[pid]; mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
         resolve_item<FEAT>(sc, P, pid, (fl & NEE_OCCLUDED) != 0, mh);
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         uint32_t slot = block_push(&lcount[0], r.next);
         if (r.next) next[slot] = pid;
         slot = block_push(&lcount[1], r.nee);
-        if (r.nee) nee[slot] = pid;
+        if (r.nee) nee[slot] = r.nee_entry(pid);
         block_count(&lcount[2], r.shadow);
         block_count(&lcount[3], r.mis);
         i = i2; pid = pid1; pid1 = pid2;

@@ -94,7 +94,7 @@ struct HostBackend {
             const uint32_t pid = q[i];
             const v4 o = P.ray_o[pid], d = P.ray_d[pid];
             CheckedStack stk = make_stack(); HitRec h; uint32_t nn = 0, nt = 0;
-            bvh_trace_any_form<false, (FEAT & FEAT_ALPHA) != 0>(sc, xyz(o), xyz(d), o.w, stk, h, nn, nt);
+            bvh_trace_any_form<false, (FEAT & FEAT_ALPHA) != 0>(sc, xyz(o), xyz(d), PT_INF, stk, h, nn, nt);
             nodes += nn; tris += nt;
             u4 r; r.x = hit_pack(h.prim, h.flags); r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
             const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
@@ -113,7 +113,7 @@ struct HostBackend {
             if (r.next) next[cnt(it + 1, Q_EXT)++] = pid;
             if (r.shadow) cnt(it, Q_SHADOW)++;
             if (r.mis) cnt(it, Q_MIS)++;
-            if (r.nee) Q.nee[cnt(it, Q_NEE)++] = pid;
+            if (r.nee) Q.nee[cnt(it, Q_NEE)++] = r.nee_entry(pid);
         }
     }
     void connect(uint32_t it) {
