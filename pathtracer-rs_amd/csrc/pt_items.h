@@ -198,7 +198,7 @@ struct ShadeCtx {
     PT_MEM void before_stores() const {}
 };
 
-struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; PT_MEM uint32_t nee_entry(uint32_t pid) const { return pid | (mis ? 0u : (uint32_t)NEE_Q_PRE); } }; // err_dim: a Sobol dimension >= 1024 was drawn (the reference panics, sobol.rs:177-183)
+struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; PT_MEM uint32_t nee_entry(uint32_t pid) const { return pid | (shadow ? (uint32_t)NEE_Q_SHADOW : 0u) | (mis ? (uint32_t)NEE_Q_MIS : (uint32_t)NEE_Q_PRE); } }; // err_dim: a Sobol dimension >= 1024 was drawn (the reference panics, sobol.rs:177-183)
 
 // What a shading vertex reads of its path: five 16-byte vectors out of HBM (nothing else of a path is cache-resident: a
 // pass holds tens of GB of path state).  The gfx950 shade kernel fetches the NEXT item's PathIn while it shades the
@@ -389,7 +389,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 // closest hit (prim < 0: it escaped).
 template <int FEAT>
 PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, bool occluded, const HitRec &mh) {
-    const uint32_t pid = entry & ~(uint32_t)NEE_Q_PRE;
+    const uint32_t pid = entry & NEE_Q_PID;
     if (entry & NEE_Q_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, sh_o.w, ray_o.w)
         if (!occluded) { const f3 c = mk3(P.sh_d[pid].w, P.sh_o[pid].w, P.ray_o[pid].w); const v4 Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + c, Lv.w); }
         return;
@@ -420,8 +420,8 @@ PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, bool 
 
 template <int FEAT, bool QUAD, class Stack, class Geom>
 PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t entry, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
-    const uint32_t pid = entry & ~(uint32_t)NEE_Q_PRE;
-    const uint32_t fl = (entry & NEE_Q_PRE) ? (uint32_t)(NEE_SHADOW | NEE_PRE) : P.nee2[pid].w >> 24;
+    const uint32_t pid = entry & NEE_Q_PID;
+    const uint32_t fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
     bool occluded = false;
     HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
     if (fl & NEE_SHADOW) {

@@ -202,7 +202,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     const uint32_t n_lanes = std::max(1u, be.lanes());
     // up to 2^27 paths (~35 GB of path state) per lane: HBM (288 GB) is plentiful, launches and tails are not free.  The back
     // end bounds it by its share of the memory that is free right now, so the library stays embeddable beside other users.
-    uint64_t capacity = prm.paths_per_pass ? prm.paths_per_pass : std::min<uint64_t>(1ull << 27, be.auto_capacity(n_lanes, sc_host_feat.kinds_present));
+    uint64_t capacity = std::min<uint64_t>(1ull << 27, prm.paths_per_pass ? prm.paths_per_pass : be.auto_capacity(n_lanes, sc_host_feat.kinds_present)); // (2^27: a path slot is 27 bits of a NEE-queue entry, pt_scene.h)
     if (capacity < (uint64_t)g.NX) capacity = (uint64_t)g.NX;
     if (single_pixel) capacity = std::max<uint64_t>(capacity, (uint64_t)g.NX * g.spp); // one pass: the pixel's spp paths (planned below as one row x all samples, launched as spp paths)
     const uint64_t band_rows = (uint64_t)(srow1 - srow0);

@@ -178,9 +178,10 @@ struct alignas(8) f2a { float x, y; }; // an 8-byte element of a device array (o
 
 // path-state bits (u4.z of `st`)
 enum : uint32_t { ST_DIM_MASK = 0xfffu, ST_SPECULAR = 1u << 12, ST_HAS_DIFF = 1u << 13, ST_BOUNCE_SHIFT = 16 };
-// An entry of the NEE queue: the path slot, and in bit 31 whether the record is shadow-only (NEE_PRE).  Such a record needs no flags word:
-// its kind is known from the queue, and the connect stage reads nothing of nee0 / nee1 / nee2 for it.
-enum : uint32_t { NEE_Q_PRE = 0x80000000u };
+// An entry of the NEE queue: the path slot (bits 0-26: a pass holds at most 2^27 paths) and what the record holds -- a shadow ray (bit 29),
+// a MIS ray (bit 30), shadow-only with the contribution precomputed (bit 31, NEE_PRE).  The connect stage knows which rays to fetch
+// from the entry alone (no flags word to load first), and for a shadow-only record it reads nothing of nee0 / nee1 / nee2.
+enum : uint32_t { NEE_Q_PID = 0x07ffffffu, NEE_Q_SHADOW = 0x20000000u, NEE_Q_MIS = 0x40000000u, NEE_Q_PRE = 0x80000000u };
 // nee flags (stored in nee2.w as bits)
 enum : uint32_t { NEE_SHADOW = 1u, NEE_MIS = 2u,
                   NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in (sh_d.w, sh_o.w, ray_o.w): the connect stage adds it when the ray is free

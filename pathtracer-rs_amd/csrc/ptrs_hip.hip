@@ -396,9 +396,9 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             if (!has) {
                 const uint32_t i = rf_take(&cursor, idle);
                 if (i < n) {
-                    const uint32_t entry = queue[i]; // path slot | NEE_Q_PRE
-                    pid = entry & ~(uint32_t)NEE_Q_PRE;
-                    fl = (entry & NEE_Q_PRE) ? (uint32_t)(NEE_SHADOW | NEE_PRE) : reinterpret_cast<const uint32_t *>(P.nee2 + pid)[3] >> 24;
+                    const uint32_t entry = queue[i]; // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
+                    pid = entry & NEE_Q_PID;
+                    fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
                     if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
                 } else dry = true;
             }
@@ -433,8 +433,9 @@ __device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const 
     const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
     if (*seg_count(Q, it, Q_MIS, G, b) == 0) return; // every record of the segment was shadow-only: k_connect_rf has resolved them
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
-        const uint32_t pid = queue[i];
-        if (pid & NEE_Q_PRE) continue; // shadow-only: resolved when its ray retired
+        const uint32_t entry = queue[i];
+        if (entry & NEE_Q_PRE) continue; // shadow-only: resolved when its ray retired
+        const uint32_t pid = entry & NEE_Q_PID;
         const uint32_t fl = P.nee2[pid].w >> 24;
         HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
         if (fl & NEE_MIS) { const u4 v = P.hit[pid]; mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
