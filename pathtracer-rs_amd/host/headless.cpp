@@ -25,7 +25,7 @@ static bool parse_resolution(const char *s, int &w, int &h) { // main.rs:23-33
 
 int main(int argc, char **argv) {
     std::string scene_path, out_dir, dump_path, dump_full_path, env_map_path;
-    bool default_lights = false, even_bands = false, preview = false, quiet = false;
+    bool default_lights = false, even_bands = false, preview = false, progress = false;
     int n_gpus = 1;
     int spp = 1, max_depth = 15, w = 640, h = 480; // DEFAULT_RESOLUTION common/mod.rs:14
     bool have_out = false;
@@ -43,14 +43,15 @@ int main(int argc, char **argv) {
         else if (a == "--gpus") n_gpus = std::atoi(need("--gpus")); // not a flag of the reference: split the frame's rows over N devices of this process
         else if (a == "--even_bands") even_bands = true;               // equal-height bands instead of the 1-spp cost probe
         else if (a == "--preview") preview = true;                     // DIR/render.png is rewritten after every pass (the reference pushes the partial film to tev, headless.rs:197-214)
-        else if (a == "--quiet") quiet = true;                         // no progress line
+        else if (a == "--progress") progress = true;                   // a progress line per pass (the reference's progress bar, integrator.rs:631-634); like --preview it
+                                                                       // renders through ptrs_render_progressive, which publishes the film after every pass (slower than the one-shot render)
         else if (a == "--headless") {}
         else if (a == "-c" || a == "--camera" || a == "-l" || a == "--log_level" || a == "-m" || a == "--module_log" || a == "--server") (void)need(a.c_str());
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "error: unknown flag %s\n", a.c_str()); return 2; }
         else scene_path = a;
     }
     if (scene_path.empty() || (!have_out && dump_path.empty() && dump_full_path.empty())) {
-        std::fprintf(stderr, "usage: ptrs_headless SCENE(.xml|.gltf|.glb) -o DIR [-s SPP] [-r WxH] [-d DEPTH] [--default_lights --env_map FILE.hdr] [--gpus N [--even_bands]] [--preview] [--quiet] [--headless]\n");
+        std::fprintf(stderr, "usage: ptrs_headless SCENE(.xml|.gltf|.glb) -o DIR [-s SPP] [-r WxH] [-d DEPTH] [--default_lights --env_map FILE.hdr] [--gpus N [--even_bands]] [--preview] [--progress] [--headless]\n");
         return 2;
     }
     Camera camera; RenderScene scene; std::string err;
@@ -59,7 +60,7 @@ int main(int argc, char **argv) {
     if (!dump_path.empty()) { if (!dump_scene(dump_path, camera, scene)) { std::fprintf(stderr, "error: cannot write %s\n", dump_path.c_str()); return 1; } if (!have_out) return 0; }
     int32_t sb[4];
     camera.film.get_sample_bounds(sb);
-    PathIntegrator integrator(SamplerBuilder(spp, sb), max_depth, !quiet);
+    PathIntegrator integrator(SamplerBuilder(spp, sb), max_depth, progress || preview);
     integrator.preprocess(scene);
     if (preview && have_out) integrator.on_pass = [&](uint32_t done, uint32_t total, int32_t, int32_t) {
         std::string e;

@@ -92,14 +92,14 @@ def test_cli_usage_and_errors(cli, tmp_path):
 
 
 @pytest.mark.gpu
-def test_headless_cli_preview_and_quiet_give_the_same_png(cli, tmp_path):
+def test_headless_cli_preview_gives_the_same_png(cli, tmp_path):
     """--preview rewrites DIR/render.png after every pass (render() then runs through ptrs_render_progressive, the film is
-    published pass by pass, headless.rs:197-214); --quiet renders through ptrs_render without the progress line.  The final image
-    is the same file, byte for byte."""
+    published pass by pass, headless.rs:197-214, with a progress line); the default is the one-shot ptrs_render.  The final image is the
+    same file, byte for byte."""
     a, b = tmp_path / "a", tmp_path / "b"
     a.mkdir(); b.mkdir()
     ra = subprocess.run([cli, CORNELL, "-o", str(a), "-s", "64", "-r", "64x64", "-d", "6", "--headless", "--preview"], capture_output=True, text=True)
-    rb = subprocess.run([cli, CORNELL, "-o", str(b), "-s", "64", "-r", "64x64", "-d", "6", "--headless", "--quiet"], capture_output=True, text=True)
+    rb = subprocess.run([cli, CORNELL, "-o", str(b), "-s", "64", "-r", "64x64", "-d", "6", "--headless"], capture_output=True, text=True)
     assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr, rb.stderr)
     assert "rendering: pass" in ra.stderr and "rendering: pass" not in rb.stderr
     assert (a / "render.png").read_bytes() == (b / "render.png").read_bytes()
