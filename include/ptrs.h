@@ -255,7 +255,9 @@ int ptrs_render(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderPara
  * every two seconds while render() runs (headless.rs:197-214).  After every pass of the
  * wavefront pipeline (a block of sample rows x a block of sample indices) whose film kernel has finished, the output rows
  * it touched are copied into film_inout and `fn(user, passes_done, passes_total, row_begin, row_end)` is called on the
- * calling thread; the rows hold the samples accumulated so far (rgb and weight sums: divide to display, film.rs:253-271).
+ * calling thread; the rows hold the samples accumulated so far (rgb and weight sums: divide to display, film.rs:253-271):
+ * at least those of the passes reported so far -- the copy is taken when the pass's pipeline lane is next waited for, passes
+ * behind it keep running and may already show -- and callbacks arrive in pass order.
  * The final film is bit-identical to ptrs_render's. */
 typedef void (*PtrsProgressFn)(void *user, uint32_t passes_done, uint32_t passes_total, int32_t row_begin, int32_t row_end);
 int ptrs_render_progressive(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params,

@@ -237,7 +237,8 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     PtrsStats st;
     std::memset(&st, 0, sizeof(st));
     std::vector<uint32_t> counts((size_t)(max_iters + 1u) * Q_STRIDE);
-    struct Pending { bool active = false; uint32_t it = 0, n_paths = 0; };
+    const uint32_t n_passes_total = (uint32_t)(((band_rows + rows_per_pass - 1) / rows_per_pass) * ((g.spp + samples_per_pass - 1) / samples_per_pass));
+    struct Pending { bool active = false; uint32_t it = 0, n_paths = 0, pass_no = 0; int32_t y0 = 0, y1 = 0; };
     std::vector<Pending> pending(n_lanes);
     auto finish = [&](uint32_t lane) { // collect the counters of the pass a lane ran last (waits for that lane only)
         Pending &pd = pending[lane];
@@ -251,11 +252,14 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
         }
         st.samples += pd.n_paths;
         st.passes += 1;
+        // progressive render: the pass's rows are published here, when its lane is waited for anyway (before the lane's next pass, or at
+        // the end), not right behind its launch -- the passes on the other lanes keep running meanwhile.  Passes finish in launch order
+        // (their film kernels are chained), so the callbacks arrive in pass order.
+        if (progress && progress->fn && pd.y1 > pd.y0) { be.publish_rows(film, pd.y0, pd.y1); progress->fn(progress->user, pd.pass_no + 1u, n_passes_total, pd.y0, pd.y1); }
         pd.active = false;
     };
     uint32_t pass_no = 0;
     bool null_skip_overrun = false;
-    const uint32_t n_passes_total = (uint32_t)(((band_rows + rows_per_pass - 1) / rows_per_pass) * ((g.spp + samples_per_pass - 1) / samples_per_pass));
     for (int32_t r0 = srow0; r0 < srow1; r0 += (int32_t)rows_per_pass) {
         const int32_t r1 = std::min<int32_t>(srow1, r0 + (int32_t)rows_per_pass);
         for (uint32_t s0 = 0; s0 < g.spp; s0 += (uint32_t)samples_per_pass, ++pass_no) {
@@ -284,12 +288,12 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
             const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);
             if (y1 > y0 && !single_pixel) be.film(film, y0, y1); // ordered after the previous pass's film kernel, whichever lane ran it
-            if (progress && progress->fn && y1 > y0 && !single_pixel) { be.publish_rows(film, y0, y1); progress->fn(progress->user, pass_no + 1u, n_passes_total, y0, y1); }
             if (samples_out) be.export_samples(samples_out);
-            pending[lane].active = true; pending[lane].it = it; pending[lane].n_paths = R.n_paths;
+            pending[lane].active = true; pending[lane].it = it; pending[lane].n_paths = R.n_paths; pending[lane].pass_no = pass_no;
+            pending[lane].y0 = single_pixel ? 0 : y0; pending[lane].y1 = single_pixel ? 0 : y1;
         }
     }
-    for (uint32_t l = 0; l < n_lanes; ++l) finish(l);
+    for (uint32_t k = 0; k < n_lanes; ++k) finish((pass_no + k) % n_lanes); // oldest pass first: the callbacks keep their order
     be.end(st);
     if (null_skip_overrun) st.error_flags |= PTRS_ERRFLAG_NULL_SKIPS;
     st.bvh_nodes = sc.n_nodes; st.bvh_max_depth = bvh_depth;

@@ -395,8 +395,8 @@ def test_cfg4_classroom_band_at_full_settings(ptrs, scenes):
 
 
 def test_progressive_render_publishes_the_film_pass_by_pass(ptrs):
-    """ptrs_render_progressive: after each pass the touched rows are in the host film (weights grow from pass to pass), the
-    callback sees every pass once, and the final film is bit-identical to ptrs_render's."""
+    """ptrs_render_progressive: after each pass the touched rows are in the host film (at least that pass's samples), the
+    callback sees every pass once and in order, and the final film is bit-identical to ptrs_render's."""
     cam, scene = ptrs.import_scene(CORNELL, (64, 48))
     integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(16, cam.film.get_sample_bounds()), 6, paths_per_pass=20000)  # several passes
     integ.render(cam, scene)
@@ -411,7 +411,9 @@ def test_progressive_render_publishes_the_film_pass_by_pass(ptrs):
     integ.render_progressive(cam, scene, on_pass)
     assert [d for d, _, _, _ in seen] == list(range(1, n_ref + 1)) and all(t == n_ref for _, t, _, _ in seen) and n_ref >= 4
     assert all(0 <= y0 < y1 <= 48 for _, _, y0, y1 in seen)
-    assert all(b > a for a, b in zip(sums, sums[1:])) and sums[0] > 0
+    # a pass's rows are copied out when its pipeline lane is next waited for: passes behind it may already have landed in them, so the
+    # weights never shrink from callback to callback (and grow over the render), they need not grow at every single one
+    assert all(b >= a for a, b in zip(sums, sums[1:])) and sums[0] > 0 and sums[-1] > sums[0]
     assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
     assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), ref["weight"].view(np.uint32))
 
