@@ -103,12 +103,14 @@ inline int scene_features(const HostScene &H) {
     if ((need & ~FEAT_IMG_ENV) == 0) return FEAT_IMG_ENV;
     return FEAT_FULL;
 }
-// Feature set the extension / connection kernels need: textured emission, environment light, alpha masks.
-// (A scene whose only image textures sit on materials can run the lean traversal kernels.)
+// Feature set the extension / connection kernels need: alpha masks (tested inside the traversal loop: FEAT_FULL), or only textured
+// emission / an environment light (read by the epilogue and the MIS resolve behind the loop: FEAT_IMG_ENV, whose traversal loop is the
+// lean one), or none of them.  (A scene whose only image textures sit on materials can run the lean traversal kernels.)
 inline int scene_trace_features(const HostScene &H) {
-    bool any = !H.inf_lights.empty() || H.has_alpha;
+    if (H.has_alpha) return FEAT_FULL;
+    bool any = !H.inf_lights.empty();
     for (const DLight &L : H.lights) any = any || (L.kind == PTRS_LIGHT_AREA && !L.ke_const);
-    return any ? FEAT_FULL : FEAT_SIMPLE;
+    return any ? FEAT_IMG_ENV : FEAT_SIMPLE;
 }
 
 // Output-row bands for n devices: bounds[0] = 0 <= bounds[1] <= ... <= bounds[n] = height.  Without costs the

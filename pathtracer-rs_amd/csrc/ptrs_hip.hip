@@ -1024,7 +1024,7 @@ struct HipBackend {
         } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
     }
-    void extend(uint32_t it) { t0(T_EXTEND); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
+    void extend(uint32_t it) { t0(T_EXTEND); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else if (feat_trace == FEAT_IMG_ENV) extend_t<FEAT_IMG_ENV>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void connect_t(uint32_t it) {
         dim3 g(G), b(BLOCK);
         StackSpill sp = ps->spill;
@@ -1052,7 +1052,7 @@ struct HipBackend {
         } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
 #undef PTRS_LAUNCH
     }
-    void connect(uint32_t it) { t0(T_CONNECT); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
+    void connect(uint32_t it) { t0(T_CONNECT); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else if (feat_trace == FEAT_IMG_ENV) connect_t<FEAT_IMG_ENV>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
     // The Sobol' dimensions a vertex of round `it` can draw: a path starts the round at dimension <= 3 + 8 it (two camera
     // dimensions, the skipped dimension 4, at most 8 per vertex before) and draws at most 9 further ones; the window staged
     // into LDS is the top of that range (paths below it -- long specular chains -- read the global tables).

@@ -101,7 +101,7 @@ struct HostBackend {
             if (k >= 0) Q.mat[k][cnt(it, Q_MAT0 + k)++] = pid;
         }
     }
-    void extend(uint32_t it) { if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); }
+    void extend(uint32_t it) { if (feat_trace != FEAT_SIMPLE) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); } // (FEAT_IMG_ENV: the full set gives the same results)
     void shade(uint32_t it, int kind) {
         const uint32_t *q = Q.mat[kind];
         uint32_t *next = Q.ext[(it + 1) & 1];
@@ -120,8 +120,8 @@ struct HostBackend {
         for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) {
             CheckedStack stk = make_stack(); uint32_t nn = 0, nt = 0;
             const GeomGlobal G = geom_global(sc);
-            if (sc.n_nodes4) { if (feat_trace == FEAT_FULL) connect_item<FEAT_FULL, true>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, true>(sc, G, P, Q.nee[i], stk, nn, nt); }
-            else { if (feat_trace == FEAT_FULL) connect_item<FEAT_FULL, false>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, false>(sc, G, P, Q.nee[i], stk, nn, nt); }
+            if (sc.n_nodes4) { if (feat_trace != FEAT_SIMPLE) connect_item<FEAT_FULL, true>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, true>(sc, G, P, Q.nee[i], stk, nn, nt); }
+            else { if (feat_trace != FEAT_SIMPLE) connect_item<FEAT_FULL, false>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, false>(sc, G, P, Q.nee[i], stk, nn, nt); }
             nodes += nn; tris += nt;
         }
     }
