@@ -194,6 +194,7 @@ PT_HD void draw_vertex(const CTX &X, const DSampler &S, const u4 &stv, bool nee,
 struct ShadeCtx {
     PT_MEM TriRegs tri(const DScene &sc, int32_t prim, bool want_dp) const { return load_tri_regs(sc.shade + prim, want_dp); }
     PT_MEM void light(const DScene &sc, uint32_t li, DLight &out) const { out = sc.lights[li]; }
+    PT_MEM const InfMarginal *inf_marginal(uint32_t) const { return nullptr; }
     template <int N> PT_MEM void sobol(const DSampler &S, uint64_t index, const uint32_t (&dim)[N], uint32_t scramble, float (&out)[N]) const { sobol_batch<N>(S, index, dim, scramble, out); }
     PT_MEM void before_stores() const {}
 };
@@ -274,7 +275,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         const f2 u_light = mk2(u_nee[0], u_nee[1]), u_scat = mk2(u_nee[2], u_nee[3]);
         const bool delta = light_is_delta(Lt);
         LightSample ls;
-        light_sample_li<FEAT>(sc, Lt, s.p, sp, u_light, ls);
+        light_sample_li<FEAT>(sc, Lt, s.p, sp, u_light, ls, X.inf_marginal(li));
         PT_STAMP(4, f2u(ls.pdf) + f2u(ls.wi.x) + f2u(ls.li.x) + f2u(ls.p1.x))
         f3 A = splat3(0.0f);
         float spdf = 0.0f;

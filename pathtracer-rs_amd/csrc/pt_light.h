@@ -90,10 +90,14 @@ PT_HD float dist1d_sample(const float *func, const float *cdf, float func_int, u
     return ((float)off + du) / (float)n;
 }
 
+// The environment light's marginal distribution (row integrals, their cdf, the cdf's guide table) from somewhere nearer than the
+// global pool: the gfx950 shade kernels keep it in LDS, which takes three links out of the dependent-load chain of a light sample.
+struct InfMarginal { const float *func, *cdf, *guide; };
+
 // Light::sample_li.  Returns false when the reference leaves the visibility tester unset
 // (InfiniteAreaLight with map_pdf == 0, light.rs:411-413) -- the reference would panic there.
 template <int FEAT>
-PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const SpawnPair &ref_sp, f2 u, LightSample &o) {
+PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const SpawnPair &ref_sp, f2 u, LightSample &o, const InfMarginal *im = nullptr) {
     o.p1_err = splat3(0.0f); o.p1_n = splat3(0.0f);
     if (L.kind == 0) { // point
         f3 pl = ld3(L.v);
@@ -122,8 +126,9 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const Sp
     // infinite area light
     const float *D = sc.distdata;
     float pdf_v, pdf_u; uint32_t v, dummy;
-    float d1 = dist1d_sample(D + L.fint_off, D + L.mcdf_off, L.marg_int, (uint32_t)L.nv, u.y, pdf_v, v, D + L.mguide_off, L.guide_v);
-    float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), D[L.fint_off + v], (uint32_t)L.nu, u.x, pdf_u, dummy,
+    const float *mf = im ? im->func : D + L.fint_off, *mc = im ? im->cdf : D + L.mcdf_off, *mg = im ? im->guide : D + L.mguide_off; // same tables, same values
+    float d1 = dist1d_sample(mf, mc, L.marg_int, (uint32_t)L.nv, u.y, pdf_v, v, mg, L.guide_v);
+    float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), mf[v], (uint32_t)L.nu, u.x, pdf_u, dummy,
                              D + L.cguide_off + (uint64_t)v * (L.guide_u + 1u), L.guide_u);
     float map_pdf = pdf_u * pdf_v;
     if (map_pdf == 0.0f) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; }

@@ -509,11 +509,13 @@ template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT ==
 #endif
 enum : uint32_t { SH_SOB_WORDS = PTRS_SH_SOB_WORDS, SH_TRI_V4 = PTRS_SH_TRI_V4, SH_LIGHTS = 16, SH_LIGHT_V4 = sizeof(DLight) / 16, SH_TRI_REC_V4 = sizeof(DTriShade) / 16 };
 static_assert(sizeof(DLight) % 16 == 0 && sizeof(DTriShade) % 16 == 0, "records are staged as 16-byte vectors");
-struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds; }; // Sobol' window [sob_lo, sob_lo + sob_n), nibbles staged per dimension
+struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds, marg_li; }; // marg_li: the environment light whose marginal tables are staged (0xffffffff: none)
+enum : uint32_t { SH_MARG_N = 1024, SH_MARG_WORDS = 3 * SH_MARG_N + 8 }; // row integrals [nv] | their cdf [nv + 1] | the cdf's guide [guide_v + 1], nv and guide_v <= 1024 // Sobol' window [sob_lo, sob_lo + sob_n), nibbles staged per dimension
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 PT_HD uint32_t sob_stride(uint32_t nib) { return nib * 16u + 4u; } // words per dimension; + 4: consecutive dimensions start 4 banks apart
 struct ShadeCtxLds {
-    lds_u32 *sob; lds_v4 *tris, *lights; ShadeLdsCfg cfg;
+    lds_u32 *sob; lds_v4 *tris, *lights; ShadeLdsCfg cfg; InfMarginal marg;
+    __device__ inline const InfMarginal *inf_marginal(uint32_t li) const { return li == cfg.marg_li ? &marg : nullptr; }
     __device__ inline v4 ld(lds_v4 *q) const { v4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
     __device__ inline TriRegs tri(const DScene &sc, int32_t prim, bool want_dp) const {
         if (!cfg.tri_lds) return load_tri_regs(sc.shade + prim, want_dp);
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
     __shared__ uint32_t lds_sob[SH_SOB_WORDS];
     __shared__ v4 lds_tri[SH_TRI_V4];
     __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
+    __shared__ float lds_marg[(FEAT & FEAT_INFINITE) ? SH_MARG_WORDS : 1];
     bool err_dim = false;
     if (threadIdx.x < 4) lcount[threadIdx.x] = 0;
     if (threadIdx.x == 4) finished = 0;
@@ -588,9 +591,17 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         if (cfg.tri_lds) { const v4 *g = reinterpret_cast<const v4 *>(sc.shade); for (uint32_t i = threadIdx.x; i < sc.n_prims * SH_TRI_REC_V4; i += BLOCK) lds_tri[i] = g[i]; }
         const v4 *gl = reinterpret_cast<const v4 *>(sc.lights);
         for (uint32_t i = threadIdx.x; i < cfg.n_lights_lds * SH_LIGHT_V4; i += BLOCK) lds_light[i] = gl[i];
+        if ((FEAT & FEAT_INFINITE) && cfg.marg_li != 0xffffffffu) { // the environment light's marginal distribution: 12 KB that every light sample walks first
+            const DLight &Le = sc.lights[cfg.marg_li];
+            const uint32_t nv = (uint32_t)Le.nv, gv = Le.guide_v;
+            for (uint32_t i = threadIdx.x; i < nv; i += BLOCK) lds_marg[i] = sc.distdata[Le.fint_off + i];
+            for (uint32_t i = threadIdx.x; i < nv + 1u; i += BLOCK) lds_marg[SH_MARG_N + i] = sc.distdata[Le.mcdf_off + i];
+            for (uint32_t i = threadIdx.x; i < gv + 1u; i += BLOCK) lds_marg[2u * SH_MARG_N + 1u + i] = sc.distdata[Le.mguide_off + i];
+        }
     }
     __syncthreads();
     ShadeCtxLds X; X.sob = (lds_u32 *)lds_sob; X.tris = (lds_v4 *)lds_tri; X.lights = (lds_v4 *)lds_light; X.cfg = cfg;
+    X.marg.func = lds_marg; X.marg.cdf = lds_marg + ((FEAT & FEAT_INFINITE) ? SH_MARG_N : 0); X.marg.guide = lds_marg + ((FEAT & FEAT_INFINITE) ? 2 * SH_MARG_N + 1 : 0);
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)b * seg_cap;
     const uint32_t n = *seg_count(Q, it, Q_MAT0 + MAT, G, b);
@@ -1064,6 +1075,11 @@ struct HipBackend {
         c.tri_lds = (sc.n_prims * SH_TRI_REC_V4 <= SH_TRI_V4 && opt.shade_lds) ? 1u : 0u;
         c.n_lights_lds = opt.shade_lds ? std::min<uint32_t>(sc.n_lights, SH_LIGHTS) : 0u;
         if (!opt.shade_lds) c.sob_n = 0;
+        c.marg_li = 0xffffffffu;
+        if (opt.shade_lds && !ps->H.inf_lights.empty()) {
+            const DLight &Le = ps->H.lights[ps->H.inf_lights[0]];
+            if (Le.nv >= 1 && (uint32_t)Le.nv <= SH_MARG_N && Le.guide_v >= 1 && Le.guide_v <= SH_MARG_N) c.marg_li = ps->H.inf_lights[0];
+        }
         return c;
     }
     template <int FEAT> void shade_t(uint32_t it, int kind) {
