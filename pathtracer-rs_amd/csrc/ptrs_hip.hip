@@ -487,11 +487,13 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
 // Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X.  The Matte / FEAT_SIMPLE kernel needs 183
 // registers unconstrained and fits 168 (3 waves) with 24 bytes of scratch: +1.6 % on the Cornell frame together with the
 // smaller LDS tables below (three workgroups per CU instead of two).  The mirror / glass kernels need 109-135 registers and
-// get their third wave from the LDS budget alone; the Disney / metal / substrate kernels need 191-256 and stay at 2.
+// get their third wave from the LDS budget alone; the Disney kernel with image textures (colonnade) needs 209 and still gains at
+// 168 with 112 bytes of scratch (shade kernels 39.2 -> 37.2 ms, frame +1.9 %); the other Disney / metal / substrate kernels
+// (191-256 registers) stay at 2, unmeasured or measured worse.
 #ifndef PTRS_SHADE_WAVES_MATTE
 #define PTRS_SHADE_WAVES_MATTE 3
 #endif
-template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT == FEAT_SIMPLE) ? PTRS_SHADE_WAVES_MATTE : 2 }; }; // 2: never above 256 registers (one wave per SIMD otherwise)
+template <int MAT, int FEAT> struct ShadeWaves { enum { N = ((MAT == 0 && FEAT == FEAT_SIMPLE) || (MAT == 4 && FEAT == FEAT_IMG)) ? PTRS_SHADE_WAVES_MATTE : 2 }; }; // 2: never above 256 registers (one wave per SIMD otherwise)
 
 // The shade kernels' read-only tables in LDS.  A shading vertex issues ~150 vector-memory instructions -- path state,
 // the triangle's record, 32 Sobol' table words, the light's record, spills -- and the kernel's time is the time the
