@@ -29,38 +29,46 @@ struct GeomLocal {
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { a = tris4[3u * k]; b = tris4[3u * k + 1u]; c = tris4[3u * k + 2u]; }
 };
 
+// The decision of Bounds3::intersect_p_precomp (bounds.rs:190-232) from its six plane distances (the upper ends already scaled by
+// 1 + 2 gamma(3)), gfx950 form.  The reference runs `if t_min > ty_max || ty_min > t_max { return false }`, takes the larger lower end and
+// the smaller upper end, does the same with z, and ends with `t_min < ray.t_max && t_max > 0`.  Its four interval tests are the six
+// comparisons "lower end of one axis > upper end of another", so
+//     no test fails and t_max > 0   <=>   max3(lower ends) <= min3(upper ends) and min3(upper ends) > 0:
+// the three same-axis pairs the right side adds cannot fail once every upper end is positive (lower <= upper on an axis, rounding is
+// monotone, and scaling a positive upper end by k > 1 only raises it).  Two v_max3 / v_min3 and two comparisons instead of four
+// v_max / v_min and five comparisons -- on gfx950 comparisons, selects and min / max all issue at half the rate of fp32 add / mul
+// (tools/valu_ceiling.hip), they are what the slab test's time is made of.
+// NaNs (0 * inf: the ray lies in one of the box's planes): the comparison form ignores a NaN that comes in from y or z (every comparison
+// with it is false, the running values keep their old contents) and so do v_max3 / v_min3 (IEEE maxNum / minNum); a NaN on the x axis
+// stays in the reference's running value to the end and fails the box (t_max > 0 is false for a NaN t_max; for a NaN t_min the entry
+// distance is NaN and the caller's t_entry < ray.t_max is false): the explicit `ordered` test fails the box in exactly those cases
+// (test_rays_inside_box_planes).  (+0 / -0 can come out differently in the entry distance; it is only ever compared.)
+PT_HD bool slab_finish(float tx_min, float ty_min, float tz_min, float tx_max, float ty_max, float tz_max, float &t_entry) {
+    const bool x_ordered = !__builtin_isunordered(tx_min, tx_max);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(tx_min, ty_min), tz_min);
+    const float tf = __builtin_fminf(__builtin_fminf(tx_max, ty_max), tz_max);
+    t_entry = tn;
+    return (tn <= tf) & (tf > 0.0f) & x_ordered;
+}
 // Bounds3::intersect_p_precomp (bounds.rs:190-232) on explicit box corners, split in two: everything
 // that does not depend on ray.t_max (the per-axis interval tests and `t_max_box > 0`) is decided here
 // and the entry distance returned; the caller finishes the test with `t_entry < ray.t_max`.
 PT_HD bool slab_entry6(float minx, float miny, float minz, float maxx, float maxy, float maxz, f3 o, f3 inv, const bool neg[3], float &t_entry) {
-    // straight-line form of the early-out code (same comparisons in the same order, so the same answer also when a
-    // product is NaN): 64 lanes rarely agree on which interval test fails, and a branch per test costs more than it saves
     const float k = 1.0f + 2.0f * gamma_err(3);
     float t_min = ((neg[0] ? maxx : minx) - o.x) * inv.x;
     float t_mx = ((neg[0] ? minx : maxx) - o.x) * inv.x;
     const float ty_min = ((neg[1] ? maxy : miny) - o.y) * inv.y;
     float ty_max = ((neg[1] ? miny : maxy) - o.y) * inv.y;
     t_mx *= k; ty_max *= k;
-    const bool miss_y = (t_min > ty_max) | (ty_min > t_mx);
     const float tz_min = ((neg[2] ? maxz : minz) - o.z) * inv.z;
     float tz_max = ((neg[2] ? minz : maxz) - o.z) * inv.z;
     tz_max *= k;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // `if ty_min > t_min { t_min = ty_min }` as one v_max_f32 instead of compare + select (and v_min_f32 for the upper ends).  The two forms
-    // differ only when the running value is a NaN, which the comparison keeps and max / min drop: a NaN can only enter the running values
-    // on the x axis (0 * inf: the ray lies in one of the box's x planes), the comparison form then carries it to the end and the box fails
-    // (t_mx > 0 is false for a NaN t_mx; for a NaN t_min the entry distance is NaN and every caller's t_entry < t_max is false).  The
-    // `ordered` test below fails the box in exactly those cases.  A NaN coming in from y or z is dropped by both forms.  (+0 / -0 can come
-    // out differently; the entry distance is only ever compared.)
-    const bool x_ordered = !__builtin_isunordered(t_min, t_mx);
-    t_min = __builtin_fmaxf(t_min, ty_min);
-    t_mx = __builtin_fminf(t_mx, ty_max);
-    const bool miss_z = (t_min > tz_max) | (tz_min > t_mx);
-    t_min = __builtin_fmaxf(t_min, tz_min);
-    t_mx = __builtin_fminf(t_mx, tz_max);
-    t_entry = t_min;
-    return !(miss_y | miss_z) & (t_mx > 0.0f) & x_ordered;
+    return slab_finish(t_min, ty_min, tz_min, t_mx, ty_max, tz_max, t_entry);
 #else
+    // straight-line form of the early-out code (same comparisons in the same order, so the same answer also when a
+    // product is NaN): 64 lanes rarely agree on which interval test fails, and a branch per test costs more than it saves
+    const bool miss_y = (t_min > ty_max) | (ty_min > t_mx);
     t_min = ty_min > t_min ? ty_min : t_min;
     t_mx = ty_max < t_mx ? ty_max : t_mx;
     const bool miss_z = (t_min > tz_max) | (tz_min > t_mx);

@@ -461,7 +461,7 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
         stack_bound2 = depth2;
     }
     // small scenes are walked out of LDS in pair form (cheaper steps when a fetch costs nothing), the rest in quad form
-    H.use_quad = 4u * H.nodes2.size() + 3u * n_tris > PAIR_FORM_MAX_V4;
+    H.use_quad = 7u * H.nodes2.size() + 9u * n_tris > PAIR_FORM_MAX_V4;
     if (node_form == 2) H.use_quad = true; // (pair form cannot be forced: the kernels only walk it out of LDS)
     if (H.use_quad) { H.nodes2.clear(); H.stack_bound = stack_bound4; } else { H.nodes4.clear(); H.stack_bound = stack_bound2; }
     if (H.use_quad && H.nodes4.size() > QUAD_TOP_NODES) {

@@ -240,11 +240,38 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     std::memset(&st, 0, sizeof(st));
     std::vector<uint32_t> counts((size_t)(max_iters + 1u) * Q_STRIDE);
     const uint32_t n_passes_total = (uint32_t)(((band_rows + rows_per_pass - 1) / rows_per_pass) * ((g.spp + samples_per_pass - 1) / samples_per_pass));
-    struct Pending { bool active = false; uint32_t it = 0, n_paths = 0, pass_no = 0; int32_t y0 = 0, y1 = 0; };
+    struct Pending { bool active = false, open = false; uint32_t it = 0, n_paths = 0, pass_no = 0; int32_t y0 = 0, y1 = 0; };
     std::vector<Pending> pending(n_lanes);
+    bool null_skip_overrun = false;
+    auto round = [&](uint32_t i) {
+        be.extend(i);                                                     // closest hit + emission / miss / depth cut + material buckets
+        for (int k = 0; k < 6; ++k) if (kinds_present[k]) be.shade(i, k); // one specialised kernel per material bucket
+        be.connect(i);                                                    // shadow + MIS queries, resolve into L
+    };
+    // A path can outlive max_depth + 1 rounds only through null-BSDF skips (`bounces -= 1`, integrator.rs:434-439), which only glass
+    // can produce.  Such a pass is enqueued with a few rounds to spare (a round nobody reaches costs its launches: the kernels look at
+    // the round's alive flag and leave) and stays OPEN: whether it needs more is asked when its lane is waited for anyway -- before
+    // the lane's next pass, or at the end -- not right behind its launch, where the question would stall the host until the pass is
+    // through and keep the other lanes empty (round 2: glass scenes ran their lanes one after the other).  The film follows then.
+    const uint32_t spare_rounds = kinds_present[PTRS_MAT_GLASS] ? 6u : 0u;
+    auto close_pass = [&](uint32_t lane) {
+        Pending &pd = pending[lane];
+        if (!pd.active || !pd.open) return;
+        be.select(lane);
+        uint32_t it = pd.it;
+        if (spare_rounds) { // (only null-BSDF skips can keep a path alive beyond max_depth + 1 rounds: other scenes are not asked)
+            while (it < max_iters && be.read_count(it, Q_EXT) != 0) { round(it); ++it; }
+            if (it == max_iters && be.read_count(it, Q_EXT) != 0) null_skip_overrun = true; // paths still alive: never dropped silently
+        }
+        pd.it = it;
+        if (pd.y1 > pd.y0) be.film(film, pd.y0, pd.y1); // ordered after the previous pass's film kernel, whichever lane ran it
+        if (samples_out) be.export_samples(samples_out);
+        pd.open = false;
+    };
     auto finish = [&](uint32_t lane) { // collect the counters of the pass a lane ran last (waits for that lane only)
         Pending &pd = pending[lane];
         if (!pd.active) return;
+        close_pass(lane);
         be.select(lane);
         be.read_counts(counts.data(), pd.it + 1u);
         for (uint32_t i = 0; i <= pd.it && i < max_iters + 1u; ++i) {
@@ -261,12 +288,13 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
         pd.active = false;
     };
     uint32_t pass_no = 0;
-    bool null_skip_overrun = false;
     for (int32_t r0 = srow0; r0 < srow1; r0 += (int32_t)rows_per_pass) {
         const int32_t r1 = std::min<int32_t>(srow1, r0 + (int32_t)rows_per_pass);
         for (uint32_t s0 = 0; s0 < g.spp; s0 += (uint32_t)samples_per_pass, ++pass_no) {
             const uint32_t s1 = (uint32_t)std::min<uint64_t>(g.spp, (uint64_t)s0 + samples_per_pass);
             const uint32_t lane = pass_no % n_lanes;
+            // (an open pass is closed -- asked for more rounds, its film kernel enqueued -- when its lane comes round again: passes close in pass
+            // order, the order their film kernels are chained in)
             finish(lane);
             be.select(lane);
             R.row0 = r0; R.row1 = r1; R.s0 = s0; R.s1 = s1;
@@ -275,24 +303,13 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             be.pass_begin(R);
             be.generate();
             uint32_t it = 0;
-            auto round = [&](uint32_t i) {
-                be.extend(i);                                                     // closest hit + emission / miss / depth cut + material buckets
-                for (int k = 0; k < 6; ++k) if (kinds_present[k]) be.shade(i, k); // one specialised kernel per material bucket
-                be.connect(i);                                                    // shadow + MIS queries, resolve into L
-            };
-            for (; it < fixed_iters; ++it) round(it);
-            // A path can outlive max_depth+1 rounds only through null-BSDF skips (`bounces -= 1`,
-            // integrator.rs:434-439), which only glass can produce: poll the queue in that case.
-            if (kinds_present[PTRS_MAT_GLASS]) {
-                while (it < max_iters && be.read_count(it, Q_EXT) != 0) { round(it); ++it; }
-                if (it == max_iters && be.read_count(it, Q_EXT) != 0) null_skip_overrun = true; // paths still alive: never dropped silently
-            }
+            for (; it < std::min(fixed_iters + spare_rounds, max_iters); ++it) round(it);
             // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
             const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);
-            if (y1 > y0 && !single_pixel) be.film(film, y0, y1); // ordered after the previous pass's film kernel, whichever lane ran it
-            if (samples_out) be.export_samples(samples_out);
             pending[lane].active = true; pending[lane].it = it; pending[lane].n_paths = R.n_paths; pending[lane].pass_no = pass_no;
-            pending[lane].y0 = single_pixel ? 0 : y0; pending[lane].y1 = single_pixel ? 0 : y1;
+            pending[lane].y0 = (single_pixel || y1 <= y0) ? 0 : y0; pending[lane].y1 = (single_pixel || y1 <= y0) ? 0 : y1;
+            pending[lane].open = true;
+            if (!spare_rounds) close_pass(lane); // nothing to ask: the film kernel follows the rounds at once
         }
     }
     for (uint32_t k = 0; k < n_lanes; ++k) finish((pass_no + k) % n_lanes); // oldest pass first: the callbacks keep their order

@@ -46,7 +46,7 @@ struct alignas(16) DNode4 {
 };
 static_assert(sizeof(DNode4) == 128, "node4");
 enum : uint32_t { QUAD_TOP_NODES = 85 }; // 1 + 4 + 16 + 64 records of the quad tree's top, kept in LDS by the traversal kernels (10.6 KB)
-enum : uint32_t { PAIR_FORM_MAX_V4 = 1024 }; // largest scene (4 vectors per pair node + 3 per triangle) the kernels stage into LDS
+enum : uint32_t { PAIR_FORM_MAX_V4 = 1536 }; // largest scene the traversal kernels stage into LDS, in 16-byte vectors of its LDS form: 7 per pair node (its planes per axis and ray sign), 9 per triangle (three permuted copies)
 enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0xffffffffu, REF_FIRST_MASK = 0x07ffffffu, REF_COUNT_SHIFT = 27, REF_MAX_LEAF = 16 };
 
 enum : uint32_t { TRI_HAS_NORMAL = 1, TRI_HAS_TANGENT = 2, TRI_REVERSE = 8, TRI_SWAPS = 16, TRI_DEGENERATE = 32, TRI_HAS_ALPHA = 64,
@@ -216,7 +216,9 @@ struct DQueues {
     uint32_t *ext[2];          // ping-pong extension-ray queues
     uint32_t *mat[Q_NUM_MAT];  // one shade queue per material kind
     uint32_t *nee;             // paths with a pending next-event-estimation record this round
-    uint32_t *counts;          // [iters][Q_STRIDE]
+    uint32_t *counts;          // [iters][Q_STRIDE][G]
+    uint32_t *tickets;         // [iters][Q_STRIDE][...]: segment tickets of the persistent queue kernels, one set of counters per launch of a pass
+    uint32_t *alive;           // [iters]: round i still has paths (set by the shade kernels of round i - 1)
     unsigned long long *stats; // [CNT_NUM]
 };
 

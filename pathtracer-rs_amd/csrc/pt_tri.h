@@ -30,16 +30,9 @@ PT_HD RayShear ray_shear(f3 d) {
     return S;
 }
 
-// returns true and fills h when the ray (o, shear of d, t_max) hits triangle (p0,p1,p2) -- shape.rs:85-185
-PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
-    f3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
-    const int kz = S.kz;
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    p0t = mk3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
-    p1t = mk3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
-    p2t = mk3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
-    const float sx = S.sx, sy = S.sy, sz = S.sz;
+// The test proper on vertices that are already translated to the ray origin and permuted to (kx, ky, kz) -- shape.rs:110-185.
+// (Callers that keep permuted copies of the triangles -- the LDS-form traversal kernels -- skip the nine component selects.)
+PT_HD bool tri_test_perm(f3 p0t, f3 p1t, f3 p2t, float sx, float sy, float sz, float t_max, TriHit &h) {
     p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
     p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
     p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
@@ -73,6 +66,17 @@ PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2,
     if (t <= delta_t) return false;
     h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
     return true;
+}
+// returns true and fills h when the ray (o, shear of d, t_max) hits triangle (p0,p1,p2) -- shape.rs:85-185
+PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
+    f3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    const int kz = S.kz;
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    p0t = mk3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
+    p1t = mk3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
+    p2t = mk3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
+    return tri_test_perm(p0t, p1t, p2t, S.sx, S.sy, S.sz, t_max, h);
 }
 // The same with 1/d already at hand (traversal computes it for the slab tests): sz = 1/d[kz] is one of its components --
 // the same division, so the same bits -- which saves one of the six IEEE divisions of a ray's set-up.

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -39,7 +40,9 @@ struct Options {
     int refill = -1;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend; -1 = by scene (32 with phase voting and no alpha masks, else 16)
     int refill_connect = -1;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
-    int grid_mult = 1;        // workgroups per pass in units of the resident capacity (8 per CU)
+    int grid_mult = 8;        // queue segments (one wave each) per pass: CUs x 8 x grid_mult, i.e. 16384 on MI355X at the default (Cornell single-lane frame: 4: 252 ms, 8: 216, 16: 222)
+    int grid_pct = 100;       // share of its resident capacity a persistent launch takes: below 100 a kernel leaves wave slots to the kernels of the other pipeline lanes
+    int persist = 1;          // queue kernels are launched with the workgroups that fit the machine at once (occupancy x CUs); 0: with 8 per CU, the hardware's maximum (A/B hook)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
     int vote = -1;            // lane-refill traversal kernels: each step runs the phase (node visit / triangle test) most lanes of the wave are in.
                               // 0 off, 1 both kernels, 2 extension kernel only, -1 = by scene: 1 for quad-form scenes (colonnade extend 86 -> 56 ms), 2 for the LDS-resident
@@ -55,7 +58,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 16}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
+    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"grid_pct", &Options::grid_pct, 10, 100}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -67,39 +70,78 @@ const OptionDesc k_options[] = {
         }                                                                                                         \
     } while (0)
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 256, WAVES = BLOCK / 64;
 
-// Segmented queues.  Every queue is split into G segments (G = grid size of the pass); workgroup b
-// appends only to segment b and, in the next kernel, workgroup b consumes segment b.  Slots are
-// handed out from an LDS counter (one ds_add per wave), the segment length is written once at the
-// end of the kernel: no global atomics at all.  (The first version used one global counter per
-// queue: ~16 M returning atomics per frame on a single address, which serialises at ~90/us and
-// was the bottleneck of every stage.)
-__device__ inline uint32_t block_push(uint32_t *lds_counter, bool pred) {
+// Segmented queues, one WAVE per segment.  Every queue of a pass is split into G segments; the wave that consumes segment s of
+// one stage appends only to segment s of the next, so a segment has one writer at a time and its slots come from a counter the
+// wave keeps in a scalar register (one s_bcnt1 per push): no atomics on the data path at all, neither global (the first version:
+// ~16 M returning atomics per frame on one address) nor LDS (round 2: one ds_add per wave and push, plus a workgroup barrier
+// per segment).  The queue kernels are PERSISTENT: a launch holds only as many workgroups as fit the machine at once
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs), and each of their waves takes segment numbers from a per-launch ticket
+// counter until the G segments are gone (one returning global atomic per wave and segment, asked for one segment ahead).  With a
+// workgroup per segment and G = 2048 workgroups on 5-7 resident per CU, the second scheduling round of every launch ran a third
+// full (time-average occupancy 8 / ceil(8 / c) waves per SIMD); now every wave slot works until the tickets run out, and the
+// tail is one wave-segment (G / resident waves is 1.3-2.7 at the default grid_mult).
+__device__ inline uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); } // set bits of m below this lane
+__device__ inline uint32_t wave_push(uint32_t &count, bool pred) { // slot for every lane with pred; count is wave-uniform
     const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return 0xffffffffu;
-    const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(lds_counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t slot = count + lanes_below(m);
+    count += (uint32_t)__popcll(m);
+    return slot;
 }
-__device__ inline void block_count(uint32_t *lds_counter, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m != 0ull && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(lds_counter, (uint32_t)__popcll(m));
+// The segment a wave works on next, or a number >= G when the launch has none left.  One counter for the whole launch would take one
+// returning atomic per segment on ONE address, ~18 ns apiece on MI355X: 0.3 ms for G = 16384, which is what a kernel of the thin late
+// rounds of a pass then costs however little it has to do (measured: 11 of Cornell's 16 rounds, 30 ms of a 200 ms frame).  So the
+// launch has TK_SUB counters 128 bytes apart, each handing out a contiguous range of ceil(G / TK_SUB) segments; a wave reads all of
+// them with one load (lane k reads counter k), takes a ticket from the first open one at or after its home counter, and moves on as
+// ranges run out.  The atomics of a launch spread over TK_SUB addresses, and a wave sees the launch exhausted with a single load.
+enum : uint32_t { TK_SUB = 64, TK_SUB_STRIDE = 32, TK_LAUNCH_WORDS = TK_SUB * TK_SUB_STRIDE };
+__device__ inline uint32_t seg_next(uint32_t *ticket, uint32_t G) {
+    const uint32_t per = (G + TK_SUB - 1u) / TK_SUB; // every counter hands out `per` numbers; those at or beyond G (the last counters' surplus) are skipped
+    const uint32_t home = (blockIdx.x * WAVES + (threadIdx.x >> 6)) & (TK_SUB - 1u);
+    for (;;) {
+        // lane k reads counter k (a device-coherent load: the counters only grow, a stale value costs one atomic that comes back empty); which
+        // counters are still open is a lane mask.  In one asm statement with one temporary: written in C++ the scan's per-lane values are
+        // hoisted out of the callers' segment loops and cost every kernel ~10 vector registers.
+        uint32_t tmp; unsigned long long open;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 7, %0\n\tglobal_load_dword %0, %0, %2 sc1\n\ts_waitcnt vmcnt(0)\n\tv_cmp_gt_u32 %1, %3, %0"
+                     : "=&v"(tmp), "=s"(open) : "s"(ticket), "s"(per) : "memory");
+        static_assert(TK_SUB_STRIDE * 4u == 128u, "the asm above shifts the lane id by 7");
+        if (open == 0ull) return 0xffffffffu;
+        const unsigned long long rot = home ? ((open >> home) | (open << (64u - home))) : open; // the home counter first
+        const uint32_t c = (home + (uint32_t)__ffsll((long long)rot) - 1u) & (TK_SUB - 1u);
+        uint32_t t = 0;
+        if (__lane_id() == 0) t = atomicAdd(ticket + c * TK_SUB_STRIDE, 1u);
+        t = rfl(t);
+        const uint32_t s = c * per + t;
+        if (t < per && s < G) return s;
+        // the counter ran out between the load and the atomic, or the number is one of its surplus: look again
+    }
 }
-// counts[(row * Q_STRIDE + q) * G + b]
-__device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uint32_t G, uint32_t b) { return Q.counts + ((size_t)row * Q_STRIDE + (size_t)q) * G + b; }
+// counts[(row * Q_STRIDE + q) * G + s]
+__device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uint32_t G, uint32_t s) { return Q.counts + ((size_t)row * Q_STRIDE + (size_t)q) * G + s; }
+enum { TK_EXTEND = 0, TK_CONNECT = 1, TK_SHADE0 = 2, TK_EPILOGUE = 9, TK_RESOLVE = 10 }; // tickets[(row * Q_STRIDE + TK_*) * TK_LAUNCH_WORDS]: the counters of one launch of a pass
+// A round nobody reaches (every path has ended: rounds are enqueued without asking, and for scenes with null-BSDF skips a few more
+// than max_depth + 1) costs its launches only: each kernel looks at the flag and leaves.
+// (Q.alive[row]: the round's "some path is still alive" flag, set by the shade kernels of the round before)
+__device__ inline bool round_is_dead(const DQueues &Q, uint32_t it) { return it > 0u && rfl(Q.alive[it]) == 0u; }
 
-// Quad nodes with the top of the tree (the first `ktop` records, breadth-first) in LDS and the rest in global memory.
-// The LDS pointer keeps its address space in the type: with two generic pointers the compiler folds both paths into one
-// generic-address (flat) load, which is slower than either.
+// Geometry sources of the traversal kernels.  LDS pointers keep their address space in the type: with two generic pointers the
+// compiler folds both paths into one generic-address (flat) load, which is slower than either.
+// Records sit in LDS at an ODD number of 16-byte vectors apart (7 per LDS-form node, 9 per quad node): a ds_read_b128 is served in
+// four groups of 16 lanes, 256 bytes = 16 vector slots per LDS cycle, and lanes of a group that read different records conflict
+// when their slots coincide.  At the records' natural strides (4 and 8 vectors) all pair nodes share 4 slots per vector and all
+// quad nodes 2 (measured: 2.4-3.7 conflict cycles per LDS instruction); at an odd stride 16 consecutive records cover all 16 slots
+// (0.5-0.6 measured).
 typedef __attribute__((address_space(3))) const v4 lds_v4;
+__device__ inline v4 lds_ld(lds_v4 *q) { v4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
+enum : uint32_t { TOP_LDS_STRIDE = 9 };
+// Quad nodes with the top of the tree (the first `ktop` records, breadth-first) in LDS and the rest in global memory.
 struct GeomTop {
     lds_v4 *top; const v4 *nodesv; const DTri *tris; uint32_t ktop;
     __device__ inline void node8(uint32_t i, v4 *o) const {
-        if (i < ktop) { lds_v4 *q = top + 8u * i; for (int k = 0; k < 8; ++k) { o[k].x = q[k].x; o[k].y = q[k].y; o[k].z = q[k].z; o[k].w = q[k].w; } }
+        if (i < ktop) { lds_v4 *q = top + TOP_LDS_STRIDE * i; for (int k = 0; k < 8; ++k) o[k] = lds_ld(q + k); }
         else { const v4 *q = nodesv + 8u * i; for (int k = 0; k < 8; ++k) o[k] = q[k]; }
     }
     __device__ inline void node(uint32_t, v4 &, v4 &, v4 &, v4 &) const {}
@@ -131,22 +173,23 @@ struct LdsStack { // records are packed into one 64-bit word (ref | entry distan
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
-// Workgroup b generates the paths of its own segment: chunks of 256 consecutive path slots are dealt
-// round-robin to the G segments (coalesced state access per wave, even load across workgroups).
-__global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCamera C, DPaths P, DQueues Q, uint32_t seg_cap) {
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    const uint32_t chunks = (R.n_paths + BLOCK - 1) / BLOCK;
-    uint32_t *seg = Q.ext[0] + (size_t)b * seg_cap;
+// Wave s generates the paths of segment s: chunks of 64 consecutive path slots are dealt round-robin to the G segments
+// (coalesced state access per wave -- 1 KB per state array and chunk -- and an even load across segments).
+__global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCamera C, DPaths P, DQueues Q, uint32_t seg_cap, uint32_t G) {
+    const uint32_t lane = threadIdx.x & 63u, s = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (s >= G) return;
+    const uint32_t chunks = (R.n_paths + 63u) / 64u;
+    uint32_t *seg = Q.ext[0] + (size_t)s * seg_cap;
     uint32_t n = 0;
-    for (uint32_t c = b; c < chunks; c += G) {
-        const uint32_t pid = c * BLOCK + threadIdx.x;
+    for (uint32_t c = s; c < chunks; c += G) {
+        const uint32_t pid = c * 64u + lane;
         if (pid < R.n_paths) {
             generate_item(R, S, C, P, pid);
-            seg[(c / G) * BLOCK + threadIdx.x] = pid;
+            seg[(c / G) * 64u + lane] = pid;
         }
-        n += (c * BLOCK + BLOCK <= R.n_paths) ? BLOCK : (R.n_paths - c * BLOCK);
+        n += (c * 64u + 64u <= R.n_paths) ? 64u : (R.n_paths - c * 64u);
     }
-    if (threadIdx.x == 0) *seg_count(Q, 0, Q_EXT, G, b) = n;
+    if (lane == 0) *seg_count(Q, 0, Q_EXT, G, s) = n;
 }
 
 // Ray source: (ro, rd) indexed by path slot, ro.w = t_max.  ANY: write occl[pid]; else write hits[pid].
@@ -170,78 +213,6 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene sc, StackSpill spill, co
     if (counters_on) { atomicAdd(&stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&stats[CNT_TRIS], (unsigned long long)nt); }
 }
 
-// Extension rays: closest-hit traversal, then the epilogue of integrator.rs:418-431 and the
-// wavefront-ballot bucketing of surviving paths by material kind (one ballot + one atomic per wave
-// and bucket).
-// Stage the scene's nodes and leaf-ordered triangles into LDS as 16-byte vectors (GEOM = capacity in
-// vectors; host guarantees 4*n_nodes2 + 3*n_prims <= GEOM).
-template <int GEOM>
-__device__ inline GeomLocal stage_geometry(const DScene &sc, v4 *lds) {
-    const uint32_t nn4 = 4u * sc.n_nodes2, nt4 = 3u * sc.n_prims;
-    const v4 *gn = reinterpret_cast<const v4 *>(sc.nodes2), *gt = reinterpret_cast<const v4 *>(sc.tris);
-    for (uint32_t i = threadIdx.x; i < nn4; i += BLOCK) lds[i] = gn[i];
-    for (uint32_t i = threadIdx.x; i < nt4; i += BLOCK) lds[nn4 + i] = gt[i];
-    __syncthreads();
-    GeomLocal G; G.nodes4 = lds; G.tris4 = lds + nn4;
-    return G;
-}
-
-template <int FEAT, int DEPTH, bool OVF, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_extend(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
-    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
-    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
-    __shared__ uint32_t lcount[8];
-    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
-    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
-    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
-    const uint32_t n = *seg_count(Q, it, Q_EXT, G, b);
-    uint32_t nn = 0, nt = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
-        const uint32_t pid = queue[i];
-        const v4 o = P.ray_o[pid], d = P.ray_d[pid];
-        LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-        HitRec h;
-        if (GEOM > 0) bvh_trace_g<false, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, xyz(o), xyz(d), PT_INF, stk, h, nn, nt); // pair nodes in LDS (ray_o.w is not the ray's t_max: pt_scene.h)
-        else bvh_trace_g<true, false, (FEAT & FEAT_ALPHA) != 0>(GG, sc, xyz(o), xyz(d), PT_INF, stk, h, nn, nt);           // quad nodes through L1/L2
-        u4 r; r.x = hit_pack(h.prim, h.flags); r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2);
-        P.hit[pid] = r;
-        const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
-        for (int m = 0; m < 6; ++m) { // wavefront-ballot bucketing by material kind
-            if (!(kinds_mask & (1u << m))) continue;
-            const uint32_t slot = block_push(&lcount[m], k == m);
-            if (k == m) Q.mat[m][(size_t)b * seg_cap + slot] = pid;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6 && (kinds_mask & (1u << threadIdx.x))) *seg_count(Q, it, Q_MAT0 + (int)threadIdx.x, G, b) = lcount[threadIdx.x];
-    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
-}
-
-// ---- lane-refill variant of the extension trace (quad-node scenes) --------------------------------------------------
-// A wave of k_extend runs as long as its longest ray while finished lanes idle: on a 262 k-triangle scene only 21 % of
-// the VALU lanes are active (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).  Here a lane that finishes its ray stores the hit
-// and, once at least `thresh` lanes of the wave are idle, takes the next ray of the workgroup's queue segment from an
-// LDS cursor.  The per-path epilogue (emission, environment, material bucketing) would run with a handful of lanes each
-// time, so it moves to k_epilogue, which walks the same segment with full waves afterwards.
-// Per-lane ray state of the refill kernels: plain scalars on purpose (a struct with the sign array in it made hipcc
-// produce a 20 % slower loop).
-#define RF_DECL f3 r_o = mk3(0, 0, 0), r_inv = mk3(1, 1, 1); bool r_neg[3] = {false, false, false}; RayShear r_shear; r_shear.kz = 2; r_shear.sx = r_shear.sy = 0.0f; r_shear.sz = 1.0f; \
-                float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE;
-#define RF_START(O, D, TMAX) { r_o = (O); const f3 d_ = (D); r_tmax = (TMAX); r_inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); \
-                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_shear = ray_shear_inv(d_, r_inv); \
-                r_h.prim = -1; r_h.t = r_tmax; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; r_hit = false; r_cur = 0; }
-// next index of the workgroup's segment for every idle lane of the wave (one LDS atomic per wave)
-__device__ inline uint32_t rf_take(uint32_t *cursor, unsigned long long idle) {
-    const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)idle) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(idle));
-    base = (uint32_t)__shfl((int)base, leader);
-    return base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-}
-
 // One step of every lane's ray.  vote = 0: the while-while loop (descend to a leaf with all lanes that are still at inner
 // nodes, then that leaf's triangles): a wave waits for its slowest descent and its fattest leaf.  vote = 1: the wave looks at
 // what its lanes need next -- a node visit or a triangle test -- and runs the one more lanes are waiting for, ONE visit or ONE
@@ -260,12 +231,165 @@ __device__ inline uint32_t first_lane_64() { return (int)__lane_id() == __ffsll(
 #define PT_COUNT_NODE(c)
 #define PT_COUNT_TRI(c, k)
 #endif
+// ---- LDS form: a small scene resolved by ray class --------------------------------------------------------------------------
+// On gfx950 only fp32 add / sub / mul / fma and the plain bit operations issue at the full rate (one wave64 instruction per
+// ~2.2 cycles and SIMD, two waves side by side); comparisons, v_cndmask, min / max, shifts, integer mads, fp64 and packed fp32 go
+// through one port at one per ~4.2 cycles (tools/valu_ceiling.hip, profiles/r03_valu_ceiling.json).  The pair-node visit of round 2
+// spent 45 of its 95 vector instructions in that class: twelve selects that pick each axis' near and far plane by the sign of the
+// ray direction, fourteen comparisons, eight min / max, ten more for the visiting order; the triangle test 18 selects for the
+// permutation that makes |d| largest in z.  A scene that lives in LDS can hold the result of those selects instead:
+//   * node i = 7 vectors: per axis the record (child 0 near, child 0 far, child 1 near, child 1 far) twice -- for rays going up
+//     and for rays going down that axis -- and (ref0, ref1, 1 << split axis, -); a lane reads the three records of ITS signs
+//     (the byte offsets are per-ray constants) and never selects a plane.  A missing second child is the box (+inf, -inf).
+//   * references are LDS byte addresses (interior) or REF_LEAF | (count - 1) << 27 | byte offset of the leaf's first triangle
+//     record: no index arithmetic in the loop.
+//   * the triangles' 48-byte records three times, vertex components rotated so that (kx, ky, kz) come first, second, third for
+//     kz = 0, 1, 2; the ray keeps its origin permuted the same way and the address of its copy.
+// Cornell: 29 nodes x 112 B + 3 x 36 x 48 B = 8.4 KB.  Same arithmetic on the same values in the same order as pair_visit /
+// leaf_step: same bits (test_traversal_kernel_variants..., test_rays_inside_box_planes).
+enum : uint32_t { LN_V4 = 7, LN_BYTES = LN_V4 * 16u, LT_BYTES = 48u };
+struct LdsGeom { uint32_t root, tri0, tri_copy; }; // LDS byte addresses: node 0, triangle copy 0; bytes per triangle copy
+typedef __attribute__((address_space(3))) const u4 lds_u4;
+__device__ inline v4 lds_at(uint32_t addr) { return lds_ld((lds_v4 *)(uintptr_t)addr); }
+__device__ inline uint32_t lds_form_ref(uint32_t ref, uint32_t base) {
+    if (ref == REF_NONE) return REF_NONE;
+    if (ref & REF_LEAF) return (ref & ~(uint32_t)REF_FIRST_MASK) | ((ref & REF_FIRST_MASK) * LT_BYTES);
+    return base + ref * LN_BYTES;
+}
+// GEOM = capacity in vectors; the host guarantees LN_V4 * n_nodes2 + 9 * n_prims <= GEOM.  The caller's barrier makes the copy visible.
+__device__ inline LdsGeom stage_lds_form(const DScene &sc, v4 *lds) {
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_v4 *)lds;
+    const uint32_t nn = sc.n_nodes2, nt = sc.n_prims;
+    for (uint32_t w = threadIdx.x; w < nn * LN_V4; w += BLOCK) {
+        const uint32_t i = w / LN_V4, v = w - i * LN_V4;
+        const float *f = reinterpret_cast<const float *>(sc.nodes2 + i); // c0min[3] c0max[3] c1min[3] c1max[3] ref0 ref1 axis -
+        const uint32_t ref0 = f2u(f[12]), ref1 = f2u(f[13]), axis = f2u(f[14]);
+        v4 r;
+        if (v < 6u) {
+            const uint32_t a = v >> 1;
+            const bool down = (v & 1u) != 0;
+            const float lo0 = f[a], hi0 = f[3u + a];
+            const float lo1 = ref1 != REF_NONE ? f[6u + a] : PT_INF, hi1 = ref1 != REF_NONE ? f[9u + a] : -PT_INF;
+            r.x = down ? hi0 : lo0; r.y = down ? lo0 : hi0; r.z = down ? hi1 : lo1; r.w = down ? lo1 : hi1;
+        } else { r.x = u2f(lds_form_ref(ref0, base)); r.y = u2f(lds_form_ref(ref1, base)); r.z = u2f(axis < 3u ? 1u << axis : 0u); r.w = 0.0f; }
+        lds[w] = r;
+    }
+    v4 *lt = lds + nn * LN_V4;
+    for (uint32_t w = threadIdx.x; w < 9u * nt; w += BLOCK) {
+        const uint32_t kz = w / (3u * nt), rem = w - kz * 3u * nt, k = rem / 3u, v = rem - k * 3u;
+        const uint32_t kx = kz == 2u ? 0u : kz + 1u, ky = kx == 2u ? 0u : kx + 1u;
+        const float *f = reinterpret_cast<const float *>(sc.tris + k); // p0[3] p1[3] p2[3] prim flags alpha_tex
+        float o[4];
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t d = 4u * v + j; // dword of the record
+            if (d < 9u) { const uint32_t vert = d / 3u, c = d - vert * 3u; o[j] = f[vert * 3u + (c == 0u ? kx : (c == 1u ? ky : kz))]; }
+            else o[j] = f[d];
+        }
+        v4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+        lt[w] = r;
+    }
+    LdsGeom G; G.root = base; G.tri0 = base + nn * LN_BYTES; G.tri_copy = nt * LT_BYTES;
+    return G;
+}
+// Per-lane state of an LDS-form ray, plain scalars (see RF_DECL): origin, 1 / d, the origin permuted to (kx, ky, kz), the shear,
+// the byte offsets of the ray's three plane records inside a node, its sign bits, the address of its triangle copy.
+#define LF_DECL f3 l_o = mk3(0, 0, 0), l_inv = mk3(1, 1, 1), l_op = mk3(0, 0, 0); float l_sx = 0.0f, l_sy = 0.0f, l_sz = 1.0f; uint32_t l_ox = 0, l_oy = 32, l_oz = 64, l_neg = 0, l_tri = 0;
+#define LF_START(LG, O, D, TMAX) { l_o = (O); const f3 d_ = (D); r_tmax = (TMAX); l_inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); \
+                const bool nx_ = l_inv.x < 0.0f, ny_ = l_inv.y < 0.0f, nz_ = l_inv.z < 0.0f; l_neg = (nx_ ? 1u : 0u) | (ny_ ? 2u : 0u) | (nz_ ? 4u : 0u); \
+                l_ox = nx_ ? 16u : 0u; l_oy = ny_ ? 48u : 32u; l_oz = nz_ ? 80u : 64u; \
+                const RayShear sh_ = ray_shear_inv(d_, l_inv); l_sx = sh_.sx; l_sy = sh_.sy; l_sz = sh_.sz; \
+                const int kx_ = sh_.kz == 2 ? 0 : sh_.kz + 1, ky_ = kx_ == 2 ? 0 : kx_ + 1; l_op = mk3(comp(l_o, kx_), comp(l_o, ky_), comp(l_o, sh_.kz)); \
+                l_tri = (LG).tri0 + (uint32_t)sh_.kz * (LG).tri_copy; \
+                r_h.prim = -1; r_h.t = r_tmax; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; r_hit = false; r_cur = (LG).root; }
+
+// pair_visit on the LDS form: both children's slab tests from the ray's three plane records, the far child stacked with its entry
+// distance when both are hit (pop-time re-test, accelerator.rs:372), the visiting order from the split axis' sign bit.
+template <class Stack>
+__device__ inline void lf_node_visit(uint32_t &cur, f3 o, f3 inv, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t negbits, float t_max, Stack &stack, uint32_t &n_nodes) {
+    const v4 X = lds_at(cur + ox), Y = lds_at(cur + oy), Z = lds_at(cur + oz), Rf = lds_at(cur + 96u);
+    const float k = 1.0f + 2.0f * gamma_err(3);
+    n_nodes += 2;
+    float t0, t1;
+    bool h0 = slab_finish((X.x - o.x) * inv.x, (Y.x - o.y) * inv.y, (Z.x - o.z) * inv.z, ((X.y - o.x) * inv.x) * k, ((Y.y - o.y) * inv.y) * k, ((Z.y - o.z) * inv.z) * k, t0);
+    bool h1 = slab_finish((X.z - o.x) * inv.x, (Y.z - o.y) * inv.y, (Z.z - o.z) * inv.z, ((X.w - o.x) * inv.x) * k, ((Y.w - o.y) * inv.y) * k, ((Z.w - o.z) * inv.z) * k, t1);
+    h0 = h0 & (t0 < t_max); h1 = h1 & (t1 < t_max);
+    const uint32_t ref0 = f2u(Rf.x), ref1 = f2u(Rf.y);
+    const bool second_first = (negbits & f2u(Rf.z)) != 0u;
+    // (h0 & h1, h0 | h1 on the lane masks themselves -- s_and_b64 / s_or_b64 -- instead of the 0 / 1 integers in vector registers the
+    // compiler makes of two booleans that feed several branches)
+    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+    if (__builtin_amdgcn_inverse_ballot_w64(m0 & m1)) { stack.push(second_first ? ref0 : ref1, second_first ? t0 : t1); cur = second_first ? ref1 : ref0; }
+    else if (__builtin_amdgcn_inverse_ballot_w64(m0 | m1)) cur = h0 ? ref0 : ref1;
+    else cur = pop_next_ref<false>(stack, t_max);
+}
+// leaf_step on the LDS form: ONE triangle of the leaf, from the ray's permuted copy.
+template <bool ALPHA>
+__device__ inline bool lf_leaf_step(const DScene &sc, uint32_t &leaf, f3 op, float sx, float sy, float sz, uint32_t tri_base, float &t_max, HitRec &out, bool &hit, uint32_t &n_tris, bool any_rt) {
+    const uint32_t first = leaf & REF_FIRST_MASK, rest = (leaf >> REF_COUNT_SHIFT) & 15u; // byte offset of this triangle's record; triangles after this one
+    leaf = rest ? leaf - (1u << REF_COUNT_SHIFT) + LT_BYTES : REF_NONE;
+    const v4 ta = lds_at(tri_base + first), tb = lds_at(tri_base + first + 16u), tc = lds_at(tri_base + first + 32u);
+    const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
+    ++n_tris;
+    TriHit h;
+    if (tri_test_perm(mk3(ta.x - op.x, ta.y - op.y, ta.z - op.z), mk3(ta.w - op.x, tb.x - op.y, tb.y - op.z), mk3(tb.z - op.x, tb.w - op.y, tc.x - op.z), sx, sy, sz, t_max, h) && !(flags & TRI_DEGENERATE)) {
+        if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) return false;
+        if (any_rt) { out.prim = 0; hit = true; return true; }
+        hit = true; t_max = h.t;
+        out.prim = (int32_t)prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2; out.flags = flags;
+    }
+    return false;
+}
+// rf_step for the LDS form (vote: the phase most lanes are in, one visit or one triangle; else descend to a leaf, then its triangles)
+template <bool VOTE, bool ALPHA, class Stack>
+__device__ inline void lf_step(const DScene &sc, uint32_t &r_cur, f3 l_o, f3 l_inv, f3 l_op, float l_sx, float l_sy, float l_sz, uint32_t l_ox, uint32_t l_oy, uint32_t l_oz, uint32_t l_neg, uint32_t l_tri,
+                               float &r_tmax, HitRec &r_h, bool &r_hit, Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt, StepCount &sc_n) {
+    if (VOTE) {
+        const bool at_node = (int32_t)r_cur >= 0, at_leaf = (int32_t)r_cur < -1; // leaf references have bit 31 set; lanes without a ray hold REF_NONE = -1
+        const uint32_t n_node = rfl((uint32_t)__popcll(__ballot(at_node))), n_leaf = rfl((uint32_t)__popcll(__ballot(at_leaf))); // (scalar registers: the comparison is an s_cmp)
+        if (n_node >= n_leaf) {
+            if (at_node) { PT_COUNT_NODE(sc_n) lf_node_visit(r_cur, l_o, l_inv, l_ox, l_oy, l_oz, l_neg, r_tmax, stk, nn); }
+        } else if (at_leaf) {
+            PT_COUNT_TRI(sc_n, 1u)
+            const bool done = lf_leaf_step<ALPHA>(sc, r_cur, l_op, l_sx, l_sy, l_sz, l_tri, r_tmax, r_h, r_hit, nt, any_rt);
+            if (done) r_cur = REF_NONE; else if (r_cur == REF_NONE) r_cur = pop_next_ref<false>(stk, r_tmax);
+        }
+        return;
+    }
+    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { PT_COUNT_NODE(sc_n) lf_node_visit(r_cur, l_o, l_inv, l_ox, l_oy, l_oz, l_neg, r_tmax, stk, nn); }
+    if (r_cur != REF_NONE) {
+        bool done = false;
+        while (!done && r_cur != REF_NONE) { PT_COUNT_TRI(sc_n, 1u) done = lf_leaf_step<ALPHA>(sc, r_cur, l_op, l_sx, l_sy, l_sz, l_tri, r_tmax, r_h, r_hit, nt, any_rt); }
+        r_cur = done ? REF_NONE : pop_next_ref<false>(stk, r_tmax);
+    }
+}
+
+__device__ inline GeomTop stage_top(const DScene &sc, v4 *lds, bool top) {
+    const GeomGlobal GG0 = geom_global(sc);
+    GeomTop GG; GG.top = (lds_v4 *)lds; GG.nodesv = GG0.nodesv; GG.tris = GG0.tris; GG.ktop = 0;
+    if (top) { GG.ktop = sc.n_nodes4 < QUAD_TOP_NODES ? sc.n_nodes4 : (uint32_t)QUAD_TOP_NODES; for (uint32_t i = threadIdx.x; i < 8u * GG.ktop; i += BLOCK) lds[TOP_LDS_STRIDE * (i >> 3) + (i & 7u)] = GG0.nodesv[i]; }
+    return GG;
+}
+
+// ---- lane-refill traversal kernels ------------------------------------------------------------------------------------
+// A wave that traced 64 rays in lock step would run as long as its longest ray while finished lanes idle: on a 262 k-triangle
+// scene only 21 % of the VALU lanes were active (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).  Here a lane that finishes its ray
+// stores the hit and, once at least `thresh` lanes of the wave are idle, takes the next ray of the wave's queue segment (the
+// cursor is a scalar register of the wave).  The per-path epilogue (emission, environment, material bucketing) would run with
+// a handful of lanes each time, so it runs behind the segment's last ray with full waves (epilogue_wave).
+// Per-lane ray state of the refill kernels: plain scalars on purpose (a struct with the sign array in it made hipcc
+// produce a 20 % slower loop).
+#define RF_DECL f3 r_o = mk3(0, 0, 0), r_inv = mk3(1, 1, 1); bool r_neg[3] = {false, false, false}; RayShear r_shear; r_shear.kz = 2; r_shear.sx = r_shear.sy = 0.0f; r_shear.sz = 1.0f; \
+                float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE;
+#define RF_START(O, D, TMAX) { r_o = (O); const f3 d_ = (D); r_tmax = (TMAX); r_inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); \
+                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_shear = ray_shear_inv(d_, r_inv); \
+                r_h.prim = -1; r_h.t = r_tmax; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; r_hit = false; r_cur = 0; }
+
 template <bool VOTE, bool QUAD, bool ALPHA, class Stack, class Geom>
 __device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
                                Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt, StepCount &sc_n) {
     if (VOTE) {
-        const bool at_node = (int32_t)r_cur >= 0, at_leaf = r_cur != REF_NONE && (int32_t)r_cur < 0; // leaf references have bit 31 set; lanes without a ray hold REF_NONE
-        const int n_node = __builtin_popcountll(__ballot(at_node)), n_leaf = __builtin_popcountll(__ballot(at_leaf));
+        const bool at_node = (int32_t)r_cur >= 0, at_leaf = (int32_t)r_cur < -1; // leaf references have bit 31 set; lanes without a ray hold REF_NONE = -1
+        const uint32_t n_node = rfl((uint32_t)__popcll(__ballot(at_node))), n_leaf = rfl((uint32_t)__popcll(__ballot(at_leaf))); // (scalar registers: the comparison is an s_cmp)
         if (n_node >= n_leaf) {
             if (at_node) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
         } else if (at_leaf) {
@@ -285,154 +409,150 @@ __device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur,
 }
 
 template <int FEAT>
-__device__ inline void epilogue_segment(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t *lcount); // below, with k_epilogue
+__device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t G, uint32_t s); // below, with k_epilogue
 template <int FEAT>
-__device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap); // below, with k_resolve
+__device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t G, uint32_t s); // below, with k_resolve
 
 // Waves per SIMD the traversal kernels are compiled for.  The quad-form kernels without alpha masks sit at the edge of 96
 // registers (5 waves), and a few registers more cost a wave and 4 % of the kernel's time (colonnade k_connect_rf: 92 -> 101
 // registers, 36.7 -> 38.2 ms): the hint pins them at 5, the small LDS-resident pair form at 6 (74-80 registers).  The others
 // are left to the compiler (0 = no hint): LDS holds them at 4 waves anyway, or the full feature set needs 110-120 registers.
-template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 256 ? 6 : ((GEOM == 0 && DEPTH == 8 && FEAT == FEAT_SIMPLE) ? 5 : 0) }; };
+template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? 6 : ((GEOM == 0 && DEPTH == 8 && FEAT == FEAT_SIMPLE) ? 5 : 0) }; };
+template <int DEPTH, int GEOM> struct TravLds { enum { TOP = GEOM == 0 && DEPTH == 8, V4 = GEOM > 0 ? GEOM : (TOP ? TOP_LDS_STRIDE * QUAD_TOP_NODES : 1) }; }; // quad form with the small stack column: the tree's top lives in LDS
 
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
-__global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask) {
-    constexpr bool TOP = GEOM == 0 && DEPTH == 8; // quad form with the small stack column: the tree's top lives in LDS
+__global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask, uint32_t Gn, uint32_t *ticket) {
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
-    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
-    __shared__ uint32_t cursor, lcount[8];
-    GeomLocal GL; const GeomGlobal GG0 = geom_global(sc);
-    if (threadIdx.x == 0) cursor = 0;
-    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
-    GeomTop GG; GG.top = (lds_v4 *)lds_geom; GG.nodesv = GG0.nodesv; GG.tris = GG0.tris; GG.ktop = 0;
-    if (TOP) { GG.ktop = sc.n_nodes4 < QUAD_TOP_NODES ? sc.n_nodes4 : (uint32_t)QUAD_TOP_NODES; for (uint32_t i = threadIdx.x; i < 8u * GG.ktop; i += BLOCK) lds_geom[i] = GG0.nodesv[i]; }
-    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
-    const uint32_t Gn = gridDim.x, b = blockIdx.x;
-    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
-    const uint32_t n = *seg_count(Q, it, Q_EXT, Gn, b);
+    __shared__ v4 lds_geom[TravLds<DEPTH, GEOM>::V4];
+    if (round_is_dead(Q, it)) return;
+    LdsGeom LG; LG.root = LG.tri0 = LG.tri_copy = 0;
+    const GeomTop GG = stage_top(sc, lds_geom, TravLds<DEPTH, GEOM>::TOP);
+    if (GEOM > 0) LG = stage_lds_form(sc, lds_geom);
+    __syncthreads(); // the only barrier of the kernel: from here on the four waves of the workgroup are independent
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-    uint32_t nn = 0, nt = 0, pid = 0; StepCount stepc;
-    bool has = false, dry = n == 0; // has: the lane holds an unfinished ray; dry: the segment has no rays left for this wave
-    RF_DECL
-    for (;;) {
-        if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this kernel
-            u4 v; v.x = hit_pack(r_h.prim, r_h.flags); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-            P.hit[pid] = v;
-            has = false;
-        }
-        const unsigned long long idle = __ballot(!has);
-        if (!dry && (uint32_t)__popcll(idle) >= thresh) {
-            if (!has) {
-                const uint32_t i = rf_take(&cursor, idle);
-                if (i < n) {
+    uint32_t nn = 0, nt = 0; StepCount stepc;
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
+        const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)s * seg_cap;
+        const uint32_t n = rfl(*seg_count(Q, it, Q_EXT, Gn, s));
+        uint32_t cursor = 0; // next entry of the segment: wave-uniform, a scalar register
+        bool has = false;    // the lane holds an unfinished ray
+        uint32_t pid = 0;
+        RF_DECL LF_DECL // (per segment: nothing of a ray is live across the epilogue; quad-form kernels use the RF set, LDS-form kernels the LF set)
+        for (;;) {
+            if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this loop
+                u4 v; v.x = hit_pack(r_h.prim, r_h.flags); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
+                P.hit[pid] = v;
+                has = false;
+            }
+            const unsigned long long idle = __ballot(!has);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (cursor < n && n_idle >= thresh) {
+                const uint32_t i = cursor + lanes_below(idle);
+                if (!has && i < n) {
                     pid = queue[i];
                     const v4 ov = P.ray_o[pid], dv = P.ray_d[pid];
-                    RF_START(xyz(ov), xyz(dv), PT_INF)
+                    if (GEOM > 0) LF_START(LG, xyz(ov), xyz(dv), PT_INF) else RF_START(xyz(ov), xyz(dv), PT_INF)
                     stk.clear(); has = true;
-                } else dry = true;
+                }
+                cursor += n_idle;
             }
-            if (cursor >= n) dry = true; // lanes that still hold rays learn that the segment is exhausted
+            if (!__any(has)) break; // every ray of the segment is retired
+            do { // steps until enough lanes are through their rays: only then is there something to retire or refill
+                if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+            // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
+            // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
+            // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
+            } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
         }
-        if (!__any(has)) break; // every ray of the segment this wave could get is retired
-        do { // steps until a lane finishes its ray: only then is there something to retire or refill
-            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
-            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
-        // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
-        // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
-        // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
-        } while (VOTE && __any(has && r_cur != REF_NONE) && (dry || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
+        // The segment's epilogue runs here, behind the wave's last ray, unless kinds_mask = 0 leaves it to k_epilogue: the hits it
+        // reads were written a moment ago by this wave (L2), and its memory latency hides behind the other waves' traversal
+        // instead of filling a kernel of its own.  (The fence orders this wave's hit stores before the loads of other lanes.)
+        if (kinds_mask) { __threadfence_block(); epilogue_wave<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, Gn, s); }
     }
-    // The segment's epilogue runs here, behind the workgroup's last ray, unless kinds_mask = 0 leaves it to k_epilogue: the hits
-    // it reads were written a moment ago by this workgroup (L2), and its memory latency hides behind the other workgroups'
-    // traversal instead of filling a kernel of its own.
-    if (kinds_mask) { __syncthreads(); epilogue_segment<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, lcount); }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
 // The two scene queries of a pending NEE record with lane refill: a lane walks the shadow ray (any hit), then the MIS
-// ray (closest hit) of its record and leaves the answers in the path state (NEE_OCCLUDED in nee2.w, the MIS hit in
-// `hit`, which the shade stage has consumed by now); k_resolve turns them into radiance with full waves.
+// ray (closest hit) of its record.  Shadow-only records (NEE_PRE) are resolved when their ray retires; for the others the
+// answers go to the path state (NEE_OCCLUDED in nee2.w, the MIS hit in `hit`, which the shade stage has consumed by now) and
+// resolve_wave turns them into radiance with full waves behind the segment's last ray.
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
-__global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t fused_resolve) {
-    constexpr bool TOP = GEOM == 0 && DEPTH == 8;
+__global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t fused_resolve, uint32_t Gn, uint32_t *ticket) {
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
-    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : (TOP ? 8 * QUAD_TOP_NODES : 1)];
-    __shared__ uint32_t cursor;
-    GeomLocal GL; const GeomGlobal GG0 = geom_global(sc);
-    if (threadIdx.x == 0) cursor = 0;
-    GeomTop GG; GG.top = (lds_v4 *)lds_geom; GG.nodesv = GG0.nodesv; GG.tris = GG0.tris; GG.ktop = 0;
-    if (TOP) { GG.ktop = sc.n_nodes4 < QUAD_TOP_NODES ? sc.n_nodes4 : (uint32_t)QUAD_TOP_NODES; for (uint32_t i = threadIdx.x; i < 8u * GG.ktop; i += BLOCK) lds_geom[i] = GG0.nodesv[i]; }
-    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom); else __syncthreads();
-    const uint32_t Gn = gridDim.x, b = blockIdx.x;
-    const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
-    const uint32_t n = *seg_count(Q, it, Q_NEE, Gn, b);
+    __shared__ v4 lds_geom[TravLds<DEPTH, GEOM>::V4];
+    if (round_is_dead(Q, it)) return;
+    LdsGeom LG; LG.root = LG.tri0 = LG.tri_copy = 0;
+    const GeomTop GG = stage_top(sc, lds_geom, TravLds<DEPTH, GEOM>::TOP);
+    if (GEOM > 0) LG = stage_lds_form(sc, lds_geom);
+    __syncthreads();
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-    uint32_t nn = 0, nt = 0, pid = 0, fl = 0; StepCount stepc;
-    bool has = false, dry = n == 0, shadow_phase = false, setup = false;
-    v4 pre_c, pre_l; pre_c.x = pre_c.y = pre_c.z = pre_c.w = 0.0f; pre_l = pre_c; // NEE_PRE records: the contribution and the path's radiance, fetched with the ray
-    RF_DECL
-    for (;;) {
-        if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
-            if (shadow_phase) {
-                if (fl & NEE_PRE) { // a shadow-only record is resolved here: l += beta * nLights * ld unless the ray was blocked (integrator.rs:66-78, 444-446)
-                    if (!r_hit) { v4 o = pre_l; o.x = pre_l.x + pre_c.x; o.y = pre_l.y + pre_c.y; o.z = pre_l.z + pre_c.z; P.L[pid] = o; }
-                    has = false;
+    uint32_t nn = 0, nt = 0; StepCount stepc;
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
+        const uint32_t *__restrict__ queue = Q.nee + (size_t)s * seg_cap;
+        const uint32_t n = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
+        uint32_t cursor = 0;
+        bool has = false, shadow_phase = false, setup = false;
+        uint32_t pid = 0, fl = 0;
+        v4 pre_c, pre_l; pre_c.x = pre_c.y = pre_c.z = pre_c.w = 0.0f; pre_l = pre_c; // NEE_PRE records: the contribution and the path's radiance, fetched with the ray
+        RF_DECL LF_DECL // (per segment: nothing of a ray is live across the resolve)
+        for (;;) {
+            if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
+                if (shadow_phase) {
+                    if (fl & NEE_PRE) { // a shadow-only record is resolved here: l += beta * nLights * ld unless the ray was blocked (integrator.rs:66-78, 444-446)
+                        if (!r_hit) { v4 o = pre_l; o.x = pre_l.x + pre_c.x; o.y = pre_l.y + pre_c.y; o.z = pre_l.z + pre_c.z; P.L[pid] = o; }
+                        has = false;
+                    } else {
+                        if (r_hit) reinterpret_cast<uint32_t *>(P.nee2 + pid)[3] |= NEE_OCCLUDED << 24;
+                        if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
+                    }
                 } else {
-                if (r_hit) reinterpret_cast<uint32_t *>(P.nee2 + pid)[3] |= NEE_OCCLUDED << 24;
-                if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
+                    u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
+                    P.hit[pid] = v;
+                    has = false;
                 }
-            } else {
-                u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-                P.hit[pid] = v;
-                has = false;
             }
-        }
-        // Ray setup (five divisions) is the expensive part of taking a ray, and it runs with the lanes that need it only: a lane
-        // whose shadow ray is done waits for its MIS ray's setup until the idle and the waiting lanes together reach the refill
-        // threshold (or nobody else is working), so that one pass of the setup code serves a batch of lanes, not one or two.
-        const unsigned long long idle = __ballot(!has);
-        const bool batch = (uint32_t)__popcll(__ballot(!has || setup)) >= thresh || !__any(has && !setup);
-        if (batch && !dry && idle) {
-            if (!has) {
-                const uint32_t i = rf_take(&cursor, idle);
-                if (i < n) {
+            // Ray setup (five divisions) is the expensive part of taking a ray, and it runs with the lanes that need it only: a lane
+            // whose shadow ray is done waits for its MIS ray's setup until the idle and the waiting lanes together reach the refill
+            // threshold (or nobody else is working), so that one pass of the setup code serves a batch of lanes, not one or two.
+            const unsigned long long idle = __ballot(!has);
+            const bool batch = (uint32_t)__popcll(__ballot(!has || setup)) >= thresh || !__any(has && !setup);
+            if (batch && cursor < n && idle) {
+                const uint32_t i = cursor + lanes_below(idle);
+                if (!has && i < n) {
                     const uint32_t entry = queue[i]; // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
                     pid = entry & NEE_Q_PID;
                     fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
                     if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
-                } else dry = true;
+                }
+                cursor += (uint32_t)__popcll(idle);
             }
-            if (cursor >= n) dry = true;
+            if (batch && setup) {
+                const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
+                const v4 o = po[pid], d = pd[pid];
+                if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = reinterpret_cast<const float *>(P.ray_o + pid)[3]; pre_l = P.L[pid]; } // shade_item's packing of a shadow-only record
+                if (GEOM > 0) LF_START(LG, xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF) else RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
+                stk.clear(); setup = false;
+            }
+            if (!__any(has)) break;
+            do {
+                if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+            } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh)); // (see k_extend_rf)
         }
-        if (batch && setup) {
-            const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
-            const v4 o = po[pid], d = pd[pid];
-            if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = reinterpret_cast<const float *>(P.ray_o + pid)[3]; pre_l = P.L[pid]; } // shade_item's packing of a shadow-only record
-            RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
-            stk.clear(); setup = false;
-        }
-        if (!__any(has)) break;
-        do {
-            if (GEOM > 0) rf_step<VOTE, false, (FEAT & FEAT_ALPHA) != 0>(GL, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
-            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
-        // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
-        // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
-        // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
-        } while (VOTE && __any(has && r_cur != REF_NONE) && (dry || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
+        // records with a MIS ray are resolved behind the wave's last ray (see k_extend_rf's epilogue), unless fused_resolve = 0 leaves them to k_resolve
+        if (fused_resolve) { __threadfence_block(); resolve_wave<FEAT>(sc, P, Q, it, seg_cap, Gn, s); }
     }
-    // records with a MIS ray are resolved behind the workgroup's last ray (see k_extend_rf's epilogue), unless fused_resolve = 0 leaves them to k_resolve
-    if (fused_resolve) { __syncthreads(); resolve_segment<FEAT>(sc, P, Q, it, seg_cap); }
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
 // estimate_direct's use of the two answers (integrator.rs:66-78, 121-134) and `l += beta * nLights * ld`, full waves
 template <int FEAT>
-__device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap) {
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
-    const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
-    if (*seg_count(Q, it, Q_MIS, G, b) == 0) return; // every record of the segment was shadow-only: k_connect_rf has resolved them
-    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
+__device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t G, uint32_t s) {
+    const uint32_t *__restrict__ queue = Q.nee + (size_t)s * seg_cap;
+    const uint32_t n = rfl(*seg_count(Q, it, Q_NEE, G, s));
+    if (rfl(*seg_count(Q, it, Q_MIS, G, s)) == 0) return; // every record of the segment was shadow-only: k_connect_rf has resolved them
+    for (uint32_t i = __lane_id(); i < n; i += 64u) {
         const uint32_t entry = queue[i];
         if (entry & NEE_Q_PRE) continue; // shadow-only: resolved when its ray retired
         const uint32_t pid = entry & NEE_Q_PID;
@@ -443,18 +563,21 @@ __device__ inline void resolve_segment(const DScene &sc, const DPaths &P, const 
     }
 }
 template <int FEAT>
-__global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) { resolve_segment<FEAT>(sc, P, Q, it, seg_cap); }
+__global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t Gn, uint32_t *ticket) {
+    if (round_is_dead(Q, it)) return;
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) resolve_wave<FEAT>(sc, P, Q, it, seg_cap, Gn, s);
+}
 
 // The epilogue of one queue segment, full waves: emission / environment / depth cut (integrator.rs:418-431) and material
 // bucketing, in queue order (the shade stage's state gathers coalesce only while a segment keeps its paths in slot order).
-// lcount: 8 zeroed LDS counters of the workgroup.
 template <int FEAT>
-__device__ inline void epilogue_segment(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t *lcount) {
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)b * seg_cap;
-    const uint32_t n = *seg_count(Q, it, Q_EXT, G, b);
-    for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) {
-        const uint32_t i = i0 + threadIdx.x;
+__device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t G, uint32_t s) {
+    const uint32_t lane = __lane_id();
+    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)s * seg_cap;
+    const uint32_t n = rfl(*seg_count(Q, it, Q_EXT, G, s));
+    uint32_t cnt[6] = {0u, 0u, 0u, 0u, 0u, 0u}; // wave-uniform: scalar registers
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const uint32_t i = i0 + lane;
         int k = -1; uint32_t pid = 0;
         if (i < n) {
             pid = queue[i];
@@ -463,23 +586,24 @@ __device__ inline void epilogue_segment(const DParams &R, const DScene &sc, cons
             h.flags = hit_flags(r.x); // the two fields of the leaf record's flags the epilogue reads
             k = extension_epilogue<FEAT>(R, sc, P, pid, h);
         }
-        for (int m = 0; m < 6; ++m) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { // wavefront-ballot bucketing by material kind
             if (!(kinds_mask & (1u << m))) continue;
-            const uint32_t slot = block_push(&lcount[m], k == m);
-            if (k == m) Q.mat[m][(size_t)b * seg_cap + slot] = pid;
+            const uint32_t slot = wave_push(cnt[m], k == m);
+            if (k == m) Q.mat[m][(size_t)s * seg_cap + slot] = pid;
         }
     }
-    __syncthreads();
-    if (threadIdx.x < 6 && (kinds_mask & (1u << threadIdx.x))) *seg_count(Q, it, Q_MAT0 + (int)threadIdx.x, G, b) = lcount[threadIdx.x];
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) if (kinds_mask & (1u << m)) *seg_count(Q, it, Q_MAT0 + m, G, s) = cnt[m];
+    }
 }
 
 // The epilogue k_extend_rf leaves out when it does not run it itself (option fused_epilogue = 0).
 template <int FEAT>
-__global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap) {
-    __shared__ uint32_t lcount[8];
-    if (threadIdx.x < 8) lcount[threadIdx.x] = 0;
-    __syncthreads();
-    epilogue_segment<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, lcount);
+__global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t Gn, uint32_t *ticket) {
+    if (round_is_dead(Q, it)) return;
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) epilogue_wave<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, Gn, s);
 }
 
 
@@ -576,17 +700,14 @@ struct ShadeCtxLds {
 };
 
 template <int MAT, int FEAT>
-__global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, ShadeLdsCfg cfg) {
-    __shared__ uint32_t lcount[4]; // next, nee, shadow rays, mis rays
-    __shared__ uint32_t finished;   // waves of this workgroup that are through their items
+__global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
     __shared__ v4 lds_pf[5 * BLOCK]; // the next item's path state per thread, filled by LDS-DMA
     __shared__ uint32_t lds_sob[SH_SOB_WORDS];
     __shared__ v4 lds_tri[SH_TRI_V4];
     __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
     __shared__ float lds_marg[(FEAT & FEAT_INFINITE) ? SH_MARG_WORDS : 1];
     bool err_dim = false;
-    if (threadIdx.x < 4) lcount[threadIdx.x] = 0;
-    if (threadIdx.x == 4) finished = 0;
+    if (round_is_dead(Q, it)) return;
     {
         const uint32_t stride = sob_stride(cfg.sob_nib), nw = cfg.sob_nib * 16u;
         for (uint32_t i = threadIdx.x; i < cfg.sob_n * stride; i += BLOCK) { const uint32_t d = i / stride, w = i - d * stride; lds_sob[i] = w < nw ? S.nibtab[((size_t)(cfg.sob_lo + d) * SOBOL_NIBBLES) * 16u + w] : 0u; }
@@ -601,16 +722,9 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
             for (uint32_t i = threadIdx.x; i < gv + 1u; i += BLOCK) lds_marg[2u * SH_MARG_N + 1u + i] = sc.distdata[Le.mguide_off + i];
         }
     }
-    __syncthreads();
+    __syncthreads(); // the only barrier: the tables are staged once per workgroup, then its four waves work through segments on their own
     ShadeCtxLds X; X.sob = (lds_u32 *)lds_sob; X.tris = (lds_v4 *)lds_tri; X.lights = (lds_v4 *)lds_light; X.cfg = cfg;
     X.marg.func = lds_marg; X.marg.cdf = lds_marg + ((FEAT & FEAT_INFINITE) ? SH_MARG_N : 0); X.marg.guide = lds_marg + ((FEAT & FEAT_INFINITE) ? 2 * SH_MARG_N + 1 : 0);
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)b * seg_cap;
-    const uint32_t n = *seg_count(Q, it, Q_MAT0 + MAT, G, b);
-    // several material kernels append to the same output segments one after the other
-    const uint32_t next_base = *seg_count(Q, it + 1u, Q_EXT, G, b), nee_base = *seg_count(Q, it, Q_NEE, G, b);
-    uint32_t *next = Q.ext[(it + 1u) & 1u] + (size_t)b * seg_cap + next_base;
-    uint32_t *nee = Q.nee + (size_t)b * seg_cap + nee_base;
 #ifdef PTRS_STAMPS
     unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -619,7 +733,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
     // no registers held while they fly) before it shades the current item, and shade_item waits for them right before it issues
     // its stores (before_stores) -- by then they have had a whole vertex's time to arrive.  The queue entry is read two items
     // ahead.  Vector k of wave w sits at lds_pf[(k * 4 + w) * 64 + lane].
-    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     auto dma = [&](uint32_t p) {
         typedef __attribute__((address_space(1))) const void gptr; typedef __attribute__((address_space(3))) void lptr;
         if (FEAT & FEAT_IMAGE) __builtin_amdgcn_global_load_lds((gptr *)(P.ray_o + p), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0); // (the ray's origin is only read for the camera ray's differentials, which only image-texture lookups use)
@@ -628,73 +742,62 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         __builtin_amdgcn_global_load_lds((gptr *)(P.st + p), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr *)(P.hit + p), (lptr *)(lds_pf + (4u * 4u + wv) * 64u), 16, 0, 0);
     };
-    uint32_t i = threadIdx.x, pid = 0, pid1 = 0;
-    if (i < n) { pid = queue[i]; dma(pid); }
-    if (i + BLOCK < n) pid1 = queue[i + BLOCK];
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first item's state is in LDS
-    while (i < n) {
-        PathIn in;
-        {
-            lds_v4 *q = (lds_v4 *)lds_pf + threadIdx.x;
-            if (FEAT & FEAT_IMAGE) in.ro = X.ld(q); else in.ro = mkv4(splat3(0.0f), 0.0f);
-            in.rd = X.ld(q + BLOCK); in.beta = X.ld(q + 2 * BLOCK);
-            const v4 a = X.ld(q + 3 * BLOCK), c = X.ld(q + 4 * BLOCK);
-            in.st.x = f2u(a.x); in.st.y = f2u(a.y); in.st.z = f2u(a.z); in.st.w = f2u(a.w);
-            in.hit.x = f2u(c.x); in.hit.y = f2u(c.y); in.hit.z = f2u(c.z); in.hit.w = f2u(c.w);
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS reads are done before the next DMA overwrites the buffer
-        const uint32_t i2 = i + BLOCK;
-        if (i2 < n) dma(pid1);
-        uint32_t pid2 = 0;
-        if (i2 + BLOCK < n) pid2 = queue[i2 + BLOCK];
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
+        const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)s * seg_cap;
+        const uint32_t n = rfl(*seg_count(Q, it, Q_MAT0 + MAT, Gn, s));
+        if (n == 0) continue;
+        // several material kernels append to the same output segments one after the other
+        const uint32_t next_base = rfl(*seg_count(Q, it + 1u, Q_EXT, Gn, s)), nee_base = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
+        uint32_t *next = Q.ext[(it + 1u) & 1u] + (size_t)s * seg_cap + next_base;
+        uint32_t *nee = Q.nee + (size_t)s * seg_cap + nee_base;
+        uint32_t c_next = 0, c_nee = 0, c_shadow = 0, c_mis = 0; // the segment's output counters: wave-uniform, scalar registers
+        uint32_t i = lane, pid = 0, pid1 = 0;
+        if (i < n) { pid = queue[i]; dma(pid); }
+        if (i + 64u < n) pid1 = queue[i + 64u];
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first item's state is in LDS
+        while (i < n) {
+            PathIn in;
+            {
+                lds_v4 *q = (lds_v4 *)lds_pf + threadIdx.x;
+                if (FEAT & FEAT_IMAGE) in.ro = X.ld(q); else in.ro = mkv4(splat3(0.0f), 0.0f);
+                in.rd = X.ld(q + BLOCK); in.beta = X.ld(q + 2 * BLOCK);
+                const v4 a = X.ld(q + 3 * BLOCK), c = X.ld(q + 4 * BLOCK);
+                in.st.x = f2u(a.x); in.st.y = f2u(a.y); in.st.z = f2u(a.z); in.st.w = f2u(a.w);
+                in.hit.x = f2u(c.x); in.hit.y = f2u(c.y); in.hit.z = f2u(c.z); in.hit.w = f2u(c.w);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS reads are done before the next DMA overwrites the buffer
+            const uint32_t i2 = i + 64u;
+            if (i2 < n) dma(pid1);
+            uint32_t pid2 = 0;
+            if (i2 + 64u < n) pid2 = queue[i2 + 64u];
 #ifdef PTRS_STAMPS
-        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X, stamp_acc, stamp_last);
-        { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[9] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; } // early returns land here
+            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X, stamp_acc, stamp_last);
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[9] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; } // early returns land here
 #else
-        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X);
+            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X);
 #endif
-        err_dim = err_dim || r.err_dim;
-        uint32_t slot = block_push(&lcount[0], r.next);
-        if (r.next) next[slot] = pid;
-        slot = block_push(&lcount[1], r.nee);
-        if (r.nee) nee[slot] = r.nee_entry(pid);
-        block_count(&lcount[2], r.shadow);
-        block_count(&lcount[3], r.mis);
-        i = i2; pid = pid1; pid1 = pid2;
+            err_dim = err_dim || r.err_dim;
+            uint32_t slot = wave_push(c_next, r.next);
+            if (r.next) next[slot] = pid;
+            slot = wave_push(c_nee, r.nee);
+            if (r.nee) nee[slot] = r.nee_entry(pid);
+            c_shadow += (uint32_t)__popcll(__ballot(r.shadow));
+            c_mis += (uint32_t)__popcll(__ballot(r.mis));
+            i = i2; pid = pid1; pid1 = pid2;
+        }
+        if (lane == 0) { // the wave is the segment's only writer in this launch
+            *seg_count(Q, it + 1u, Q_EXT, Gn, s) = next_base + c_next;
+            if (c_next) Q.alive[it + 1u] = 1u;
+            *seg_count(Q, it, Q_NEE, Gn, s) = nee_base + c_nee;
+            *seg_count(Q, it, Q_SHADOW, Gn, s) += c_shadow;
+            *seg_count(Q, it, Q_MIS, Gn, s) += c_mis;
+        }
     }
-    // No barrier at the end: a wave that has finished leaves (its registers go to the next workgroup's waves); the last
-    // of the four publishes the segment's counts.  A wave's LDS atomics execute in order, so when the last wave's
-    // increment of `finished` returns 3, every push of the other three has been counted.
     if (err_dim) atomicOr(&Q.stats[CNT_ERR], (unsigned long long)PTRS_ERRFLAG_SOBOL_DIM);
 #ifdef PTRS_STAMPS
     { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[11] += t_ - stamp_last; }
-    if ((threadIdx.x & 63u) == 0) for (int k = 0; k < 12; ++k) atomicAdd(&Q.stats[CNT_STAMP0 + k], stamp_acc[k]);
+    if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&Q.stats[CNT_STAMP0 + k], stamp_acc[k]);
 #endif
-    if ((threadIdx.x & 63u) == 0 && atomicAdd(&finished, 1u) == BLOCK / 64 - 1) {
-        *seg_count(Q, it + 1u, Q_EXT, G, b) = next_base + atomicAdd(&lcount[0], 0u);
-        *seg_count(Q, it, Q_NEE, G, b) = nee_base + atomicAdd(&lcount[1], 0u);
-        *seg_count(Q, it, Q_SHADOW, G, b) += atomicAdd(&lcount[2], 0u);
-        *seg_count(Q, it, Q_MIS, G, b) += atomicAdd(&lcount[3], 0u);
-    }
-}
-
-// Shadow (any-hit) and MIS (closest-hit) queries of the pending NEE records, resolved into L.
-template <int FEAT, int DEPTH, bool OVF, int GEOM>
-__global__ __launch_bounds__(BLOCK) void k_connect(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap) {
-    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
-    __shared__ v4 lds_geom[GEOM > 0 ? GEOM : 1];
-    GeomLocal GL; const GeomGlobal GG = geom_global(sc);
-    if (GEOM > 0) GL = stage_geometry<GEOM>(sc, lds_geom);
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    const uint32_t *__restrict__ queue = Q.nee + (size_t)b * seg_cap;
-    const uint32_t n = *seg_count(Q, it, Q_NEE, G, b);
-    uint32_t nn = 0, nt = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
-        LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
-        if (GEOM > 0) connect_item<FEAT, false>(sc, GL, P, queue[i], stk, nn, nt);
-        else connect_item<FEAT, true>(sc, GG, P, queue[i], stk, nn, nt);
-    }
-    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); }
 }
 
 // totals[row*Q_STRIDE + q] = sum over segments of counts[(row*Q_STRIDE + q)*G + b]; one workgroup per (row, q)
@@ -861,11 +964,11 @@ struct PtrsScene {
     DevBuf stack_spill;  // global part of the traversal stacks (trees deeper than the LDS column), one column per resident thread
     StackSpill spill{nullptr, 0};
     size_t spill_lane_elems = 0;
-    int grid_mult = 1; // workgroups (= queue segments) per pass in units of the resident capacity (8 per CU)
+    std::map<const void *, int> occupancy; // workgroups per CU by kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor), asked once
     uint32_t stack_lds = 16; // LDS stack entries per lane: 8 when the tree allows it, else 16 (+ spill)
     // render workspace, grown on demand and reused across calls
     DevBuf ws[MAX_LANES][32];   // per pipeline lane
-    DevBuf counts[MAX_LANES], totals[MAX_LANES];
+    DevBuf counts[MAX_LANES], totals[MAX_LANES], tickets[MAX_LANES];
     DevBuf stats, table, film_tmp, samples_tmp, strat1, strat2;
     hipStream_t lane_stream[MAX_LANES] = {}; // lane 0 runs on the caller's stream, the others on these
     hipEvent_t lane_ev[MAX_LANES] = {};      // film-done per lane
@@ -875,6 +978,7 @@ struct PtrsScene {
         for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &stats, &table, &film_tmp, &samples_tmp, &strat1, &strat2}) b->release();
         for (auto &b : counts) b.release();
         for (auto &b : totals) b.release();
+        for (auto &b : tickets) b.release();
         for (auto &l : ws) for (auto &b : l) b.release();
         for (auto st : lane_stream) if (st) (void)hipStreamDestroy(st);
         for (auto e : lane_ev) if (e) (void)hipEventDestroy(e);
@@ -910,15 +1014,16 @@ struct HipBackend {
         size_t held = 0;
         for (auto &l : ps->ws) for (auto &b : l) held += b.bytes;
         uint32_t nk = 0; for (int k = 0; k < 7; ++k) nk += kinds[k] ? 1u : 0u;
-        const double per_path = 14.0 * 16.0 + (3.0 + nk) * 4.0;
-        const double budget = (double)(fr + held) * (double)opt.workspace_pct / 100.0;
+        const double per_path = 13.0 * 16.0 + 8.0 + (3.0 + nk) * 4.0; // 13 state vectors, the 8-byte film position, the queues
+        const double budget = (double)(fr + held) * (double)opt.workspace_pct / 100.0 / (double)std::max(1, share); // `share` renders divide this device's memory (ptrs_render_multi)
         const double cap = budget / (per_path * (double)lanes_n);
         return cap < 65536.0 ? 65536ull : (uint64_t)cap;
     }
-    int grid_max = 2048;
+    int share = 1;
+    int grid_max = 8192;
     uint32_t refill_connect = 16;
     bool vote = true, vote_connect = true;
-    uint32_t refill = 16; // idle-lane threshold of the lane-refill kernels; 0 = the fused k_extend / k_connect (PTRS_REFILL)
+    uint32_t refill = 16; // idle-lane threshold of the lane-refill kernels (64: a wave takes new rays only when all its lanes are idle)
     int rc = PTRS_OK;
     // timing
     struct Span { int cat; hipEvent_t a, b; };
@@ -951,25 +1056,44 @@ struct HipBackend {
     uint64_t cat_launches[T_NUM] = {0, 0, 0, 0, 0};
     void t0(int cat) { if (flags & PTRS_FLAG_TIMING) { Span s; s.cat = cat; s.a = ev(); s.b = ev(); if (s.a) (void)hipEventRecord(s.a, stream); spans.push_back(s); } ++launches; ++cat_launches[cat]; if (cat == T_EXTEND || cat == T_CONNECT) ++trace_launches; }
     void t1() { if (flags & PTRS_FLAG_TIMING) { if (spans.back().b) (void)hipEventRecord(spans.back().b, stream); } }
-    int grid_for(uint32_t n) const { uint32_t g = (n + BLOCK - 1) / BLOCK; if (g < 1) g = 1; return (int)(g > (uint32_t)grid_max ? (uint32_t)grid_max : g); }
+    int grid_for(uint32_t n) const { uint32_t g = (n + BLOCK - 1) / BLOCK; if (g < 1) g = 1; const uint32_t gm = (uint32_t)ps->n_cu * 8u; return (int)(g > gm ? gm : g); }
+
+    // Workgroups of a persistent queue kernel: what fits the machine at once (the kernel's resident workgroups per CU x CUs), never
+    // more than the segments need (4 waves = 4 segments per workgroup).  A launch that over-estimates the residency loses nothing:
+    // workgroups that start late find the ticket counter exhausted and leave.
+    uint32_t resident_wgs[T_NUM] = {0, 0, 0, 0, 0}; // last launch of each class (PtrsStats)
+    template <class F> uint32_t persistent_grid(F fn, int cat) {
+        const void *key = reinterpret_cast<const void *>(fn);
+        auto itr = ps->occupancy.find(key);
+        int per_cu;
+        if (itr == ps->occupancy.end()) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+            per_cu = nb > 8 ? 8 : nb;
+            ps->occupancy[key] = per_cu;
+        } else per_cu = itr->second;
+        if (!opt.persist) per_cu = 8;
+        const uint32_t need = (G + WAVES - 1) / WAVES, fit = std::max(1u, (uint32_t)ps->n_cu * (uint32_t)per_cu * (uint32_t)opt.grid_pct / 100u);
+        resident_wgs[cat] = fit;
+        return need < fit ? need : fit;
+    }
+    uint32_t *ticket(uint32_t it, int which) { return Q.tickets + ((size_t)it * Q_STRIDE + (size_t)which) * TK_LAUNCH_WORDS; }
 
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
-        grid_max = ps->n_cu * 8 * ps->grid_mult;
-        // measured (single lane, Mray/s): Cornell (pair form, LDS) extend-refill 5722 vs none 5560, with connect-refill 5666;
-        // colonnade (quad form) none 1517, extend 1698, both 1830
+        grid_max = ps->n_cu * 8 * opt.grid_mult;
         // phase voting: quad-node scenes gain in both traversal kernels; on the LDS pair form a step is cheap enough that the vote's
         // own instructions eat the gain in the connect kernel (+20 %), the extension kernel keeps 4 % (A/B on MI355X)
         vote = opt.vote >= 0 ? opt.vote != 0 : true;
         vote_connect = opt.vote >= 0 ? opt.vote == 1 : sc.n_nodes4 != 0;
         // idle-lane threshold: a voting wave comes back for retire / refill in batches, and with the cheap steps of the kernels without
         // alpha masks a bigger batch pays (Cornell extend 88.8 -> 85.7 ms, colonnade connect 38.2 -> 36.4 ms at 32); the full-feature
-        // kernels (classroom) are better off at 16 (extend 227 vs 233 ms)
-        refill = (uint32_t)(opt.refill >= 0 ? opt.refill : ((vote && feat_trace == FEAT_SIMPLE) ? 32 : 16));
-        refill_connect = (uint32_t)(opt.refill_connect >= 0 ? opt.refill_connect : ((vote_connect && feat_trace == FEAT_SIMPLE) ? 32 : 16));
-        geom4 = sc.n_nodes4 ? 0xffffffffu : 4u * sc.n_nodes2 + 3u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction
+        // kernels (classroom) are better off at 16 (extend 227 vs 233 ms).  0 = no refill while a lane still works (threshold 64).
+        refill = (uint32_t)(opt.refill > 0 ? opt.refill : (opt.refill == 0 ? 64 : ((vote && feat_trace == FEAT_SIMPLE) ? 32 : 16)));
+        refill_connect = (uint32_t)(opt.refill_connect > 0 ? opt.refill_connect : (opt.refill_connect == 0 ? 64 : ((vote_connect && feat_trace == FEAT_SIMPLE) ? 32 : 16)));
+        geom4 = sc.n_nodes4 ? 0xffffffffu : LN_V4 * sc.n_nodes2 + 9u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction (pt_host_scene.h)
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
-        const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + (size_t)grid_max * BLOCK) * 4; // queues: G segments rounded up to whole chunks
+        const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + ((size_t)grid_max + 1) * 64) * 4; // queues: G segments of whole 64-entry chunks
         if ((rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
         for (uint32_t l = 0; l < n_lanes && n_lanes > 1; ++l) {
             if (l > 0 && !ps->lane_stream[l] && hipStreamCreateWithFlags(&ps->lane_stream[l], hipStreamNonBlocking) != hipSuccess) { err = "cannot create a pipeline stream"; return PTRS_ERR_DEVICE; }
@@ -977,10 +1101,12 @@ struct HipBackend {
         }
         for (uint32_t l = 0; l < n_lanes; ++l) {
             DPaths Pl; DQueues Ql;
-            void **slots16[] = {(void **)&Pl.ray_o, (void **)&Pl.ray_d, (void **)&Pl.beta, (void **)&Pl.L, (void **)&Pl.st, (void **)&Pl.hit, (void **)&Pl.pfilm, (void **)&Pl.nee0,
+            void **slots16[] = {(void **)&Pl.ray_o, (void **)&Pl.ray_d, (void **)&Pl.beta, (void **)&Pl.L, (void **)&Pl.st, (void **)&Pl.hit, (void **)&Pl.nee0,
                                 (void **)&Pl.nee1, (void **)&Pl.nee2, (void **)&Pl.sh_o, (void **)&Pl.sh_d, (void **)&Pl.mis_o, (void **)&Pl.mis_d};
             int w = 0;
-            for (auto sl : slots16) { if ((rc = ps->ws[l][w].ensure(n16)) != PTRS_OK) { err = g_err + " (path state of pipeline lane " + std::to_string(l) + "; PTRS_LANES=1 halves the workspace)"; return rc; } *sl = ps->ws[l][w++].p; }
+            for (auto sl : slots16) { if ((rc = ps->ws[l][w].ensure(n16)) != PTRS_OK) { err = g_err + " (path state of pipeline lane " + std::to_string(l) + "; ptrs_set_option(\"lanes\", 1) or a smaller workspace_pct shrink the workspace)"; return rc; } *sl = ps->ws[l][w++].p; }
+            if ((rc = ps->ws[l][w].ensure((size_t)cap * 8)) != PTRS_OK) { err = g_err; return rc; }
+            Pl.pfilm = (f2a *)ps->ws[l][w++].p;
             void **slots4[] = {(void **)&Ql.ext[0], (void **)&Ql.ext[1], (void **)&Ql.nee};
             for (auto sl : slots4) { if ((rc = ps->ws[l][w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } *sl = ps->ws[l][w++].p; }
             for (int k = 0; k < Q_NUM_MAT; ++k) {
@@ -988,8 +1114,9 @@ struct HipBackend {
                 if (kinds_mask & (1u << k)) { if ((rc = ps->ws[l][w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } Ql.mat[k] = (uint32_t *)ps->ws[l][w].p; }
                 ++w;
             }
-            if ((rc = ps->counts[l].ensure((size_t)rows * Q_STRIDE * (size_t)grid_max * 4)) != PTRS_OK || (rc = ps->totals[l].ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK) { err = g_err; return rc; }
-            Ql.counts = (uint32_t *)ps->counts[l].p; Ql.stats = (unsigned long long *)ps->stats.p;
+            if ((rc = ps->counts[l].ensure((size_t)rows * Q_STRIDE * (size_t)grid_max * 4)) != PTRS_OK || (rc = ps->totals[l].ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK ||
+                (rc = ps->tickets[l].ensure(((size_t)rows * Q_STRIDE * TK_LAUNCH_WORDS + rows) * 4)) != PTRS_OK) { err = g_err; return rc; }
+            Ql.counts = (uint32_t *)ps->counts[l].p; Ql.stats = (unsigned long long *)ps->stats.p; Ql.tickets = (uint32_t *)ps->tickets[l].p; Ql.alive = Ql.tickets + (size_t)rows * Q_STRIDE * TK_LAUNCH_WORDS;
             lane_[l] = Lane{l == 0 ? stream : ps->lane_stream[l], DParams{}, Pl, Ql, 1u, 0u};
         }
         cur = 0; P = lane_[0].P; Q = lane_[0].Q;
@@ -999,71 +1126,47 @@ struct HipBackend {
         film_prev = nullptr;
         return PTRS_OK;
     }
-    // per pass: G workgroups (= queue segments), each segment holds at most seg_cap entries
+    // per pass: G queue segments (one wave each), each holds at most seg_cap entries
     void pass_begin(const DParams &R_) {
         R = R_;
-        const uint32_t chunks = (R.n_paths + BLOCK - 1) / BLOCK;
+        const uint32_t chunks = (R.n_paths + 63u) / 64u;
         G = chunks < (uint32_t)grid_max ? chunks : (uint32_t)grid_max;
         if (G < 1) G = 1;
-        seg_cap = ((chunks + G - 1) / G) * BLOCK;
+        seg_cap = ((chunks + G - 1) / G) * 64u;
         (void)hipMemsetAsync(Q.counts, 0, (size_t)rows * Q_STRIDE * G * 4, stream);
+        (void)hipMemsetAsync(Q.tickets, 0, ((size_t)rows * Q_STRIDE * TK_LAUNCH_WORDS + rows) * 4, stream); // (+ the alive flags behind them)
     }
-    void generate() { t0(T_AUX); hipLaunchKernelGGL(k_generate, dim3(G), dim3(BLOCK), 0, stream, R, S, C, P, Q, seg_cap); t1(); }
+    void generate() { t0(T_AUX); hipLaunchKernelGGL(k_generate, dim3((G + WAVES - 1) / WAVES), dim3(BLOCK), 0, stream, R, S, C, P, Q, seg_cap, G); t1(); }
+
+    // the instantiation of a traversal kernel for this scene: LDS stack depth, spill columns, geometry source, phase voting
+    typedef void (*TravFn)(DParams, DScene, StackSpill, DPaths, DQueues, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *);
+#define PTRS_PICK(K, D, O, GE) (v ? (TravFn)K<FEAT, D, O, GE, true> : (TravFn)K<FEAT, D, O, GE, false>)
+#define PTRS_PICK_ALL(K) (ps->stack_lds == 8 ? (geom4 <= 640 ? (ovf ? PTRS_PICK(K, 8, true, 640) : PTRS_PICK(K, 8, false, 640)) : geom4 <= 1536 ? (ovf ? PTRS_PICK(K, 8, true, 1536) : PTRS_PICK(K, 8, false, 1536)) : (ovf ? PTRS_PICK(K, 8, true, 0) : PTRS_PICK(K, 8, false, 0))) \
+                                              : (ovf ? PTRS_PICK(K, 16, true, 0) : PTRS_PICK(K, 16, false, 0)))
+    template <int FEAT> TravFn pick_extend(bool v, bool ovf) { return PTRS_PICK_ALL(k_extend_rf); }
+    template <int FEAT> TravFn pick_connect(bool v, bool ovf) { return PTRS_PICK_ALL(k_connect_rf); }
+#undef PTRS_PICK_ALL
+#undef PTRS_PICK
+    StackSpill lane_spill() { StackSpill sp = ps->spill; if (sp.p) sp.p += (size_t)cur * ps->spill_lane_elems; return sp; } // this lane's columns
 
     template <int FEAT> void extend_t(uint32_t it) {
-        dim3 g(G), b(BLOCK);
-        StackSpill sp = ps->spill;
-        const bool ovf = sp.p != nullptr;
-        if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
-        if (refill) {
-            const uint32_t epi_mask = opt.fused_epilogue ? kinds_mask : 0u; // non-zero: the kernel runs its segment's epilogue behind its last ray
-#define PTRS_LAUNCH(D, O, GE) do { if (vote) hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill, epi_mask); else hipLaunchKernelGGL((k_extend_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill, epi_mask); } while (0)
-            if (ps->stack_lds == 8) {
-                if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
-                else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
-                else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
-            } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
-#undef PTRS_LAUNCH
-            if (epi_mask) return;
-            t1(); t0(T_AUX); // the traversal span ends here: the epilogue is shading-side work
-            hipLaunchKernelGGL((k_epilogue<FEAT>), g, b, 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap);
-            return;
-        }
-#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_extend<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, kinds_mask, seg_cap)
-        if (ps->stack_lds == 8) {
-            if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
-            else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
-            else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
-        } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
-#undef PTRS_LAUNCH
+        const StackSpill sp = lane_spill();
+        const uint32_t epi_mask = opt.fused_epilogue ? kinds_mask : 0u; // non-zero: the kernel runs its segment's epilogue behind its last ray
+        const TravFn fn = pick_extend<FEAT>(vote, sp.p != nullptr);
+        hipLaunchKernelGGL(fn, dim3(persistent_grid(fn, T_EXTEND)), dim3(BLOCK), 0, stream, R, sc, sp, P, Q, it, seg_cap, refill, epi_mask, G, ticket(it, TK_EXTEND));
+        if (epi_mask) return;
+        t1(); t0(T_AUX); // the traversal span ends here: the epilogue is shading-side work
+        hipLaunchKernelGGL((k_epilogue<FEAT>), dim3(persistent_grid(k_epilogue<FEAT>, T_AUX)), dim3(BLOCK), 0, stream, R, sc, P, Q, it, kinds_mask, seg_cap, G, ticket(it, TK_EPILOGUE));
     }
     void extend(uint32_t it) { t0(T_EXTEND); if (feat_trace == FEAT_FULL) extend_t<FEAT_FULL>(it); else if (feat_trace == FEAT_IMG_ENV) extend_t<FEAT_IMG_ENV>(it); else extend_t<FEAT_SIMPLE>(it); t1(); }
     template <int FEAT> void connect_t(uint32_t it) {
-        dim3 g(G), b(BLOCK);
-        StackSpill sp = ps->spill;
-        const bool ovf = sp.p != nullptr;
-        if (ovf) sp.p += (size_t)cur * ps->spill_lane_elems; // this lane's columns
-        if (refill_connect) {
-            const uint32_t fused = (opt.fused_epilogue && opt.fused_resolve) ? 1u : 0u;
-#define PTRS_LAUNCH(D, O, GE) do { if (vote_connect) hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, true>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); else hipLaunchKernelGGL((k_connect_rf<FEAT, D, O, GE, false>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused); } while (0)
-            if (ps->stack_lds == 8) {
-                if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
-                else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
-                else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
-            } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
-#undef PTRS_LAUNCH
-            if (fused) return;
-            t1(); t0(T_AUX);
-            hipLaunchKernelGGL((k_resolve<FEAT>), g, b, 0, stream, sc, P, Q, it, seg_cap);
-            return;
-        }
-#define PTRS_LAUNCH(D, O, GE) hipLaunchKernelGGL((k_connect<FEAT, D, O, GE>), g, b, 0, stream, R, sc, sp, P, Q, it, seg_cap)
-        if (ps->stack_lds == 8) {
-            if (geom4 <= 256) { if (ovf) PTRS_LAUNCH(8, true, 256); else PTRS_LAUNCH(8, false, 256); }
-            else if (geom4 <= 1024) { if (ovf) PTRS_LAUNCH(8, true, 1024); else PTRS_LAUNCH(8, false, 1024); }
-            else { if (ovf) PTRS_LAUNCH(8, true, 0); else PTRS_LAUNCH(8, false, 0); }
-        } else { if (ovf) PTRS_LAUNCH(16, true, 0); else PTRS_LAUNCH(16, false, 0); }
-#undef PTRS_LAUNCH
+        const StackSpill sp = lane_spill();
+        const uint32_t fused = (opt.fused_epilogue && opt.fused_resolve) ? 1u : 0u;
+        const TravFn fn = pick_connect<FEAT>(vote_connect, sp.p != nullptr);
+        hipLaunchKernelGGL(fn, dim3(persistent_grid(fn, T_CONNECT)), dim3(BLOCK), 0, stream, R, sc, sp, P, Q, it, seg_cap, refill_connect, fused, G, ticket(it, TK_CONNECT));
+        if (fused) return;
+        t1(); t0(T_AUX);
+        hipLaunchKernelGGL((k_resolve<FEAT>), dim3(persistent_grid(k_resolve<FEAT>, T_AUX)), dim3(BLOCK), 0, stream, sc, P, Q, it, seg_cap, G, ticket(it, TK_RESOLVE));
     }
     void connect(uint32_t it) { t0(T_CONNECT); if (feat_trace == FEAT_FULL) connect_t<FEAT_FULL>(it); else if (feat_trace == FEAT_IMG_ENV) connect_t<FEAT_IMG_ENV>(it); else connect_t<FEAT_SIMPLE>(it); t1(); }
     // The Sobol' dimensions a vertex of round `it` can draw: a path starts the round at dimension <= 3 + 8 it (two camera
@@ -1084,17 +1187,19 @@ struct HipBackend {
         }
         return c;
     }
+    typedef void (*ShadeFn)(DParams, DSampler, DCamera, DScene, DPaths, DQueues, uint32_t, uint32_t, ShadeLdsCfg, uint32_t, uint32_t *);
     template <int FEAT> void shade_t(uint32_t it, int kind) {
-        dim3 g(G), b(BLOCK);
         const ShadeLdsCfg cfg = shade_cfg(it);
+        ShadeFn fn;
         switch (kind) {
-            case 0: hipLaunchKernelGGL((k_shade<0, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
-            case 1: hipLaunchKernelGGL((k_shade<1, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
-            case 2: hipLaunchKernelGGL((k_shade<2, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
-            case 3: hipLaunchKernelGGL((k_shade<3, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
-            case 4: hipLaunchKernelGGL((k_shade<4, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
-            default: hipLaunchKernelGGL((k_shade<5, FEAT>), g, b, 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg); break;
+            case 0: fn = k_shade<0, FEAT>; break;
+            case 1: fn = k_shade<1, FEAT>; break;
+            case 2: fn = k_shade<2, FEAT>; break;
+            case 3: fn = k_shade<3, FEAT>; break;
+            case 4: fn = k_shade<4, FEAT>; break;
+            default: fn = k_shade<5, FEAT>; kind = 5; break;
         }
+        hipLaunchKernelGGL(fn, dim3(persistent_grid(fn, T_SHADE)), dim3(BLOCK), 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg, G, ticket(it, TK_SHADE0 + kind));
     }
     void shade(uint32_t it, int kind) {
         t0(T_SHADE);
@@ -1246,9 +1351,8 @@ static int scene_create_impl(const PtrsSceneDesc *desc, int32_t device, PtrsScen
     // against a 16-entry column without the cache: +2 % on colonnade, +1 % on classroom).  the option stack_lds = 16 selects that
     // older layout for quad-form scenes.
     ps->stack_lds = (H.use_quad && opt.stack_lds == 16) ? 16u : 8u;
-    ps->grid_mult = opt.grid_mult;
     if (H.stack_bound > ps->stack_lds) {
-        const size_t threads = (size_t)ps->n_cu * 8 * ps->grid_mult * BLOCK;
+        const size_t threads = (size_t)ps->n_cu * 8 * BLOCK; // no launch holds more than 8 workgroups per CU
         ps->spill_lane_elems = threads * (size_t)(H.stack_bound - ps->stack_lds);
         if ((rc = ps->stack_spill.ensure(ps->spill_lane_elems * MAX_LANES * sizeof(unsigned long long))) != PTRS_OK) { delete ps; return rc; } // concurrent lanes must not share columns
         ps->spill.p = (unsigned long long *)ps->stack_spill.p; ps->spill.stride = (uint32_t)threads;
@@ -1434,7 +1538,7 @@ static int trace_rays_impl(PtrsScene *scene, uint32_t n, const float *rays, int3
     if ((rc = upload(bo, ro)) || (rc = upload(bd, rd)) || (rc = bh.ensure((size_t)n * 16)) || (rc = bc.ensure(16)) || (rc = bs.ensure(CNT_NUM * 8)) || (rc = bt.ensure((size_t)n * 4))) { bo.release(); bd.release(); bh.release(); bc.release(); bs.release(); bt.release(); return rc; }
     hipError_t e = hipMemcpy(bc.p, &n, 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(bs.p, 0, CNT_NUM * 8);
-    const uint32_t gmax = (uint32_t)scene->n_cu * 8u * (uint32_t)scene->grid_mult; // the spill columns are sized for this many workgroups
+    const uint32_t gmax = (uint32_t)scene->n_cu * 8u; // the spill columns are sized for this many workgroups
     dim3 g((n + BLOCK - 1) / BLOCK > gmax ? gmax : (n + BLOCK - 1) / BLOCK), b(BLOCK);
     hipEvent_t ea, eb; (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
     (void)hipEventRecord(ea, nullptr);
