@@ -10,16 +10,19 @@ resident in HBM.  With N GPUs the film's rows are split into N bands (strong sca
 2-row filter halo); the bands are gathered on rank 0 with one RCCL collective inside the timed region.
 `value` = BVH queries (extension + shadow + MIS rays) of the frame / step time; halo rows a band re-traces are not counted.
 
-The JSON line carries
+The timed steps run the library's default path (no per-launch events).  The JSON line carries
   roofline     -- per kernel class (traversal = k_extend* + k_connect*, shade = k_shade*): launch durations from HIP events
-                  (inside the timed steps, where passes overlap on several pipeline lanes, AND from one extra frame on a
-                  single lane, where a kernel has the GPU to itself -- the fractions use the latter), combined with the
-                  per-launch hardware counters of the same kernels committed under profiles/ (rocprofv3 --pmc passes of
-                  `bench.py --profile`, summarised by tools/prof_report.py): HBM bytes (FETCH_SIZE + WRITE_SIZE), VALU
-                  instructions and active lanes.  Top-level fields describe the class that takes the most GPU time.
-                  These kernels are bound by VALU issue under divergence, not by HBM: `bound` says so, the HBM fraction
-                  from the counters is reported beside it, and SURVEY 8(d)'s algorithmic bytes-per-ray figure is kept
-                  as `algorithmic` (it counts BVH bytes that LDS / L2 serve, not HBM).
+                  of ONE extra untimed frame on a single pipeline lane (a kernel has the GPU to itself), combined with the
+                  hardware counters of the same kernels committed under profiles/ (rocprofv3 --pmc passes of
+                  `bench.py --profile`, summarised by tools/prof_report.py; used only when the summary carries the hash
+                  of the kernel sources this run was built from).  Every fraction is bounded by 1: HBM bytes against
+                  8 TB/s; the vector-ALU time the instructions need against the MEASURED issue rates of gfx950
+                  (profiles/r03_valu_ceiling.json: fp32 add / mul / fma issue beside one comparison / select / min-max
+                  class instruction per ~4.2 cycles and SIMD), as a lo..hi pair because the counters split instructions
+                  by kind, not by issue class; what a wave's cycles went to (issuing, s_waitcnt, waiting for a slot);
+                  LDS-array cycles against CU cycles.  `bound` names what the numbers say for the class that takes the
+                  most GPU time.  SURVEY 8(d)'s algorithmic bytes-per-ray figure is kept as `algorithmic` (it counts
+                  BVH bytes that LDS / L2 serve, not HBM).
   cpu_baseline -- the oracle (C++ restatement of the reference's CPU path, kind "port") timed on this box's host
                   cores on a bounded band of the same frame.
   film_check   -- rows of the film the timed steps produced, compared with a committed oracle fixture
@@ -46,8 +49,10 @@ WORKLOADS = {
                       label="classroom %dx%d spp=%d max_depth=%d, glass + Disney dielectric + HDR environment light data/abandoned_tank_farm_04_1k.hdr (stand-in for BASELINE configs[3]; the Classroom glTF is not available offline)"),
 }
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak
-VALU_PEAK_TLANEOPS = 256 * 4 * 64 * 2.4e9 / 2.0 / 1e12  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz = 78.6 T lane-ops/s (157 TFLOP/s as FMA)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_%s.json")
+SIMDS, CUS = 1024.0, 256.0
+CLASS_B_CYCLES = 4.2                       # profiles/r03_valu_ceiling.json: one comparison / select / min-max class instruction per 4.2 cycles and SIMD; fp32 add / mul / fma issue beside them
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_%s.json")
+CEILING_FILE = os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_%s_rows.npz")
 
 
@@ -135,56 +140,179 @@ def kernel_class(name):
     return "aux"
 
 
-def load_pmc(workload):
-    """Per-class sums of the committed counter summary: {class: {launches, hbm_bytes, valu_insts, thread_cycles, ...}}, meta."""
+def load_pmc(workload, source_hash):
+    """Per-class sums of the committed counter summary, or (None, meta) when it was measured on other kernel sources."""
     path = PMC_FILE % workload
     if not os.path.exists(path):
-        return None, None
+        return None, {"file": None}
     j = json.load(open(path))
-    meta = j.get("_meta", {})
+    meta = dict(j.get("_meta", {}))
+    meta["file"] = os.path.relpath(path, ROOT)
+    meta["source_hash_now"] = source_hash
+    meta["usable"] = meta.get("source_hash") == source_hash
+    if not meta["usable"]:
+        return None, meta
     frames = max(int(meta.get("frames", 1)), 1)
     cls = {}
+    keys = ("hbm_bytes", "valu_insts", "valu_fp32_add_mul_fma", "valu_int", "salu_insts", "lds_insts")
     for name, k in j.items():
         if name.startswith("_"):
             continue
-        c = cls.setdefault(kernel_class(name), dict(launches=0.0, hbm_bytes=0.0, valu_insts=0.0, lane_insts=0.0, busy_ms=0.0, total_ms=0.0, kernels=[]))
+        c = cls.setdefault(kernel_class(name), dict(launches=0.0, lane_insts=0.0, total_ms=0.0, cycles=0.0, wave_cycles=0.0, issue=0.0, wait=0.0, stall=0.0, lds_cycles=0.0, lds_conflict=0.0,
+                                                     nb_lo=0.0, nb_hi=0.0, kernels=[], **{q: 0.0 for q in keys}))
         c["launches"] += k["calls"] / frames
-        c["hbm_bytes"] += k["hbm_bytes"] / frames
-        c["valu_insts"] += k["valu_insts"] / frames
+        for q in keys:
+            c[q] += k.get(q, 0.0) / frames
         c["lane_insts"] += k["valu_insts"] * k["lanes_per_valu_inst"] / frames
-        c["busy_ms"] += k.get("valu_busy_frac", 0.0) * k["total_ms"] / frames
         c["total_ms"] += k["total_ms"] / frames
+        cyc = k["clock_ghz_profiled"] * 1e9 * k["total_ms"] * 1e-3  # cycles the kernel's dispatches were in flight in the profiled run
+        c["cycles"] += cyc / frames
+        wc = k["waves_resident_per_simd"] * cyc * SIMDS / 4.0       # SQ_WAVE_CYCLES (quad-cycles)
+        c["wave_cycles"] += wc / frames
+        c["issue"] += k["wave_issue_frac"] * wc / frames; c["wait"] += k["wave_wait_frac"] * wc / frames; c["stall"] += k["wave_stall_frac"] * wc / frames
+        c["nb_lo"] += k["valu_class_b_share_lo"] * k["valu_insts"] / frames; c["nb_hi"] += k["valu_class_b_share_hi"] * k["valu_insts"] / frames
+        if k.get("lds_busy_frac") is not None:
+            c["lds_cycles"] += k["lds_busy_frac"] * cyc * CUS / frames
+            c["lds_conflict"] += (k.get("lds_conflict_share") or 0.0) * k["lds_busy_frac"] * cyc * CUS / frames
         c["kernels"].append(name)
     return cls, meta
 
 
-def class_roofline(name, ms_excl, launches_excl, ms_timed, launches_timed, pmc, algorithmic_bytes=None):
-    """One class: durations live, counters from the committed PMC summary (per frame, same workload)."""
-    r = {"ms_per_frame_single_lane": ms_excl, "launches_per_frame": launches_excl,
-         "avg_launch_ms_single_lane": ms_excl / max(launches_excl, 1), "avg_launch_ms_timed_overlapped": ms_timed / max(launches_timed, 1)}
+def class_roofline(name, ms_excl, launches_excl, pmc, algorithmic_bytes=None):
+    """One class: durations live (single-lane frame), counters from the committed PMC summary (per frame, same workload, same sources)."""
+    r = {"ms_per_frame_single_lane": ms_excl, "launches_per_frame": launches_excl, "avg_launch_ms_single_lane": ms_excl / max(launches_excl, 1)}
     if algorithmic_bytes is not None:
         r["algorithmic_gbs"] = algorithmic_bytes / (ms_excl * 1e-3) / 1e9 if ms_excl > 0 else 0.0
-        r["algorithmic_frac"] = r["algorithmic_gbs"] / HBM_PEAK_GBS
+        r["algorithmic_frac_of_hbm_peak"] = r["algorithmic_gbs"] / HBM_PEAK_GBS
     if pmc is None or name not in pmc:
         r["counters"] = None
         return r
     c = pmc[name]
-    ok = abs(c["launches"] - launches_excl) < 0.5  # the counters belong to this pipeline only if the launch counts agree
+    ok = abs(c["launches"] - launches_excl) < 0.5  # the counters belong to this pipeline only if the launch counts agree too
     r["counters"] = {"file_launches_per_frame": c["launches"], "matches_live_launch_count": ok, "kernels": sorted(c["kernels"])}
     if ok and ms_excl > 0:
         sec = ms_excl * 1e-3
+        clock = c["cycles"] / (c["total_ms"] * 1e-3)            # Hz, profiled run
+        simd_cycles = sec * clock * SIMDS                        # SIMD-cycles of the live single-lane frame at the profiled clock
+        nv = c["valu_insts"]
         r["hbm_bytes_per_launch"] = c["hbm_bytes"] / max(c["launches"], 1)
         r["hbm_counter_gbs"] = c["hbm_bytes"] / sec / 1e9
         r["hbm_counter_frac"] = r["hbm_counter_gbs"] / HBM_PEAK_GBS
-        r["valu_insts_per_launch"] = c["valu_insts"] / max(c["launches"], 1)
-        r["lanes_per_valu_inst"] = c["lane_insts"] / max(c["valu_insts"], 1.0)
-        r["valu_issue_frac"] = (c["valu_insts"] / sec) / (VALU_PEAK_TLANEOPS * 1e12 / 64.0)
-        r["valu_tlaneops"] = c["lane_insts"] / sec / 1e12
-        r["valu_lane_frac"] = r["valu_tlaneops"] / VALU_PEAK_TLANEOPS
-        # share of the profiled kernel time the SIMDs' VALU pipes were executing (4 x SQ_ACTIVE_INST_VALU / SIMDs / GRBM cycles, from the
-        # profiled run): a plain fp32 wave64 instruction occupies the pipe for 4 cycles, only packed / dual-issued ones reach the 2-cycle peak
-        r["valu_pipe_busy_frac_profiled"] = c["busy_ms"] / c["total_ms"] if c["total_ms"] > 0 else None
+        r["valu_insts_per_launch"] = nv / max(c["launches"], 1)
+        r["valu_ginst_per_s"] = nv / sec / 1e9
+        r["lanes_per_valu_inst"] = c["lane_insts"] / max(nv, 1.0)
+        r["valu_class_b_share_lo_hi"] = [c["nb_lo"] / max(nv, 1.0), c["nb_hi"] / max(nv, 1.0)]
+        r["valu_pipe_frac_lo_hi"] = [CLASS_B_CYCLES * max(c["nb_lo"], nv / 2.0) / simd_cycles, CLASS_B_CYCLES * max(c["nb_hi"], nv / 2.0) / simd_cycles]
+        r["valu_pipe_frac"] = 0.5 * sum(r["valu_pipe_frac_lo_hi"])
+        r["valu_ceiling_ginst_per_s"] = r["valu_ginst_per_s"] / max(r["valu_pipe_frac"], 1e-9)  # what the SIMDs could issue of this instruction mix
+        r["wave_issue_frac"] = c["issue"] / max(c["wave_cycles"], 1.0); r["wave_wait_frac"] = c["wait"] / max(c["wave_cycles"], 1.0); r["wave_stall_frac"] = c["stall"] / max(c["wave_cycles"], 1.0)
+        r["waves_resident_per_simd_profiled"] = 4.0 * c["wave_cycles"] / max(c["cycles"] * SIMDS, 1.0)
+        r["salu_per_valu"] = c["salu_insts"] / max(nv, 1.0)
+        r["lds_busy_frac"] = c["lds_cycles"] / max(c["cycles"] * CUS, 1.0) if c["lds_cycles"] else None
+        r["lds_conflict_share"] = c["lds_conflict"] / c["lds_cycles"] if c["lds_cycles"] else None
+        if r["hbm_counter_frac"] >= 0.5:
+            r["bound"] = "hbm"
+        elif r["valu_pipe_frac"] >= 0.6:
+            r["bound"] = "valu-issue"
+        elif r["lds_busy_frac"] and r["lds_busy_frac"] >= 0.6:
+            r["bound"] = "lds"
+        elif r["wave_wait_frac"] >= 0.5:
+            r["bound"] = "waitcnt"
+        else:
+            r["bound"] = "mixed"
     return r
+
+
+def collective_smoke():
+    """A child process brings up the RCCL process group at world size 1 on this GPU and runs the film gather of the N-GPU path
+    (parallel.gather_film_rows), so that the first multi-GPU run does not meet that code for the first time."""
+    import subprocess
+    code = ("import os, sys, importlib, time; sys.path.insert(0, %r); import torch, torch.distributed as dist\n"
+            "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')\n"
+            "torch.cuda.set_device(0); dev = torch.device('cuda', 0)\n"
+            "t = time.time(); dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+            "p = torch.ones(1, device=dev); dist.all_reduce(p); torch.cuda.synchronize()\n"
+            "par = importlib.import_module('pathtracer-rs_amd.parallel')\n"
+            "film = torch.arange(64 * 32 * 4, dtype=torch.float32, device=dev).reshape(64, 32, 4); ref = film.clone()\n"
+            "par.gather_film_rows(film, 64, 0, 1, bounds=[0, 64], mode='gather', force=True); torch.cuda.synchronize()\n"
+            "assert torch.equal(film, ref); dist.barrier(); dist.destroy_process_group()\n"
+            "print('ok %%.1f s' %% (time.time() - t))\n") % ROOT
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+        last = (p.stdout.strip().splitlines() or [""])[-1]
+        return {"ran": True, "ok": p.returncode == 0 and last.startswith("ok"), "detail": last if p.returncode == 0 else (p.stderr.strip()[-300:] or last),
+                "what": "nccl (= RCCL) process group at world size 1 in a child process: init, all_reduce, parallel.gather_film_rows on a 64-row film, barrier, destroy"}
+    except subprocess.TimeoutExpired:
+        return {"ran": True, "ok": False, "detail": "timed out after 120 s"}
+    except Exception as e:  # never let the smoke take the bench line down
+        return {"ran": False, "ok": False, "detail": repr(e)}
+
+
+TRACE_WORKLOADS = {"trace-colonnade": ("colonnade", (1280, 720)), "trace-classroom": ("classroom", (1920, 1080))}
+
+
+def trace_main(args):
+    """--workload trace-colonnade | trace-classroom: traversal alone on an HBM-resident tree (SURVEY 8(d)'s formula and north_star's
+    "HBM-read roofline during traversal" mean something here: the tree does not fit LDS).  Ray sets of a real frame: the camera rays
+    and the rays leaving the paths' third vertices (ptrs_render_dump_rays), traced with the frame's own extension kernel
+    (ptrs_trace_bench); the reference's precedent is benches/benchmark_pathtracer.rs:35-54."""
+    import numpy as np
+    pkg = importlib.import_module("pathtracer-rs_amd")
+    scenes = importlib.import_module("pathtracer-rs_amd.scenes")
+    name, res = TRACE_WORKLOADS[args.workload]
+    if args.node_order >= 0:
+        pkg.set_option("node_order", args.node_order)  # read at scene creation
+    cam, scene = getattr(scenes, name)(res)
+    integ = pkg.PathIntegrator(pkg.SamplerBuilder(16, cam.film.get_sample_bounds()), DEPTH)
+    integ.preprocess(scene)
+    max_rays = 8 << 20
+    sets = {"camera rays (round 0)": pkg.dump_rays(integ, cam, scene, 0, max_rays), "secondary rays (round 3)": pkg.dump_rays(integ, cam, scene, 3, max_rays)}
+    if args.profile:
+        st, _ = pkg.trace_bench(scene, sets["secondary rays (round 3)"], repeats=args.steps)
+        print("profile: %d launches of %d secondary rays" % (args.steps + 1, len(sets["secondary rays (round 3)"])))
+        return
+    src_hash = importlib.import_module("pathtracer-rs_amd.build").source_hash()
+    pmc_path = PMC_FILE % (args.workload + ("-order%d" % args.node_order if args.node_order > 0 else ""))
+    pmc = None
+    if os.path.exists(pmc_path):
+        j = json.load(open(pmc_path))
+        if j.get("_meta", {}).get("source_hash") == src_hash:
+            pmc = next((v for k, v in j.items() if k.startswith("k_extend_rf")), None)
+    res_sets = {}
+    for label, rays in sets.items():
+        pkg.trace_bench(scene, rays, repeats=max(args.warmup, 1))
+        st, hits = pkg.trace_bench(scene, rays, repeats=args.steps, want_hits=True)
+        n = len(rays)
+        check, _ = pkg.trace_rays(scene, rays[:200000])
+        same = bool(np.array_equal(check["prim"], hits["prim"][:200000]) and np.array_equal(check["b1"].view(np.uint32), hits["b1"][:200000].view(np.uint32)))
+        npr, tpr = st.nodes_visited / n, st.tris_tested / n
+        b_ray = 32.0 + 32.0 * npr + 48.0 * tpr + 16.0
+        sec = st.ms_trace * 1e-3 / args.steps
+        res_sets[label] = {"rays": n, "ms_per_launch": sec * 1e3, "mray_per_s": n / sec / 1e6, "boxes_per_ray": npr, "tris_per_ray": tpr, "algorithmic_bytes_per_ray": b_ray,
+                           "algorithmic_gbs": b_ray * n / sec / 1e9, "algorithmic_frac_of_hbm_peak": b_ray * n / sec / 1e9 / HBM_PEAK_GBS, "hits_equal_ptrs_trace_rays": same,
+                           "hit_fraction": float((hits["prim"] >= 0).mean())}
+    sec_set = res_sets["secondary rays (round 3)"]
+    roof = {"kernel": "k_extend_rf (quad nodes, top of the tree in LDS, phase voting, lane refill, persistent waves)", "bound": "hbm",
+            "achieved": sec_set["algorithmic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sec_set["algorithmic_frac_of_hbm_peak"],
+            "what": "ALGORITHMIC bytes (SURVEY 8(d): 32 B ray + 32 B per box tested + 48 B per triangle tested + 16 B hit) x rays / kernel time against the 8 TB/s HBM peak: north_star's >= 40 % target is on this figure; what HBM actually delivers is `traffic` / hbm_counter_*",
+            "traffic": None, "sets": res_sets}
+    if pmc is not None:
+        launches = pmc["calls"]
+        roof["traffic"] = pmc["hbm_bytes"] / max(launches, 1)
+        roof["hbm_counter_gbs"] = pmc["hbm_gbs"]; roof["hbm_counter_frac"] = pmc["hbm_counter_frac_of_8TBs"]; roof["l2_hit_rate"] = pmc["l2_hit_rate"]
+        roof["fetch_size_note"] = "FETCH_SIZE as rocprofv3 reports it, not doubled: the gfx950 x2 correction is calibrated for 16 B/lane streaming reads, these are 16-byte gathers of 128-byte records"
+        roof["counters"] = {k: pmc.get(k) for k in ("valu_pipe_frac_lo", "valu_pipe_frac_hi", "wave_issue_frac", "wave_wait_frac", "wave_stall_frac", "waves_resident_per_simd", "lanes_per_valu_inst", "salu_per_valu", "bound")}
+        roof["counters_from"] = os.path.relpath(pmc_path, ROOT)
+    out = {"metric": "Mray/s, traversal only, %s (%d triangles), secondary rays of a %dx%d frame at depth 3" % (name, scene.num_triangles(), res[0], res[1]),
+           "value": sec_set["mray_per_s"], "unit": "Mray/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_set["ms_per_launch"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (procedural %s scene, seeded; rays dumped from its own render)" % name,
+           "config": {"workload": "%s: k_extend_rf over the extension rays of round 0 and round 3 of a %dx%d, 16 spp frame (stand-in scene for BASELINE configs[%d])" % (args.workload, res[0], res[1], 2 if name == "colonnade" else 3),
+                      "node_order": pkg.get_option("node_order"), "options": {k: pkg.get_option(k) for k in ("grid_mult", "refill", "vote", "stack_lds")}},
+           "roofline": roof}
+    print(json.dumps(out))
 
 
 def main():
@@ -197,11 +325,15 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--paths-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-collective-smoke", action="store_true", help="N = 1: skip the child process that brings up RCCL at world size 1 and runs the film gather")
     ap.add_argument("--even-bands", action="store_true", help="N > 1: bands of equal height instead of equal cost")
     ap.add_argument("--profile", action="store_true", help="for rocprofv3 runs: render exactly --steps frames on ONE pipeline lane (no counter / warm-up frames, no JSON)")
-    ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS),
+    ap.add_argument("--node-order", type=int, default=-1, help="trace workloads: quad-node order behind the LDS-cached top (0 depth-first, 1 treelets)")
+    ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS) + sorted(TRACE_WORKLOADS),
                     help="cornell = BASELINE configs[1] (the headline); colonnade / classroom = synthetic stand-ins for configs[2] / [3]")
     args = ap.parse_args()
+    if args.workload in TRACE_WORKLOADS:
+        return trace_main(args)
 
     import numpy as np
     import torch
@@ -292,22 +424,20 @@ def main():
     cst = step(pkg.abi.FLAG_COUNTERS)
     c_rays = cst.rays
     nodes_per_ray, tris_per_ray = cst.nodes_visited / max(c_rays, 1), cst.tris_tested / max(c_rays, 1)
-    # untimed: one frame on a single pipeline lane, so that no two kernels share the machine -- each kernel class's own
-    # duration (the timed steps below overlap passes on several lanes, which stretches every kernel's span)
+    # untimed: one frame on a single pipeline lane with an event pair around every launch, so that no two kernels share the
+    # machine -- each kernel class's own duration
     with pkg.options(lanes=1):
         xst = step(pkg.abi.FLAG_TIMING)
         sync()
     for _ in range(args.warmup):
-        step(pkg.abi.FLAG_TIMING)
+        step(0)
     sync()
     t0 = time.perf_counter()
-    tot = dict(rays=0, samples=0, ms_extend=0.0, ms_connect=0.0, ms_shade_kernels=0.0, ms_aux=0.0, ms_film=0.0, extend_launches=0, connect_launches=0, shade_launches=0)
+    tot = dict(rays=0, samples=0)
     for _ in range(args.steps):
-        st = step(pkg.abi.FLAG_TIMING)
+        st = step(0)  # the library's default path: no per-launch events
         tot["rays"] += st.rays
         tot["samples"] += st.samples
-        for k in ("ms_extend", "ms_connect", "ms_shade_kernels", "ms_aux", "ms_film", "extend_launches", "connect_launches", "shade_launches"):
-            tot[k] += getattr(st, k)
     sync()
     dt = time.perf_counter() - t0
 
@@ -327,35 +457,38 @@ def main():
         rays, samples, rays_traced, rows_traced = float(vals[1]), float(vals[2]), float(vals[3]), float(vals[4])
     if rank == 0:
         b_ray = 32.0 + 32.0 * nodes_per_ray + 48.0 * tris_per_ray + 16.0
-        pmc, pmc_meta = load_pmc(args.workload) if (world == 1 and standard) else (None, None)
-        steps = args.steps
+        src_hash = importlib.import_module("pathtracer-rs_amd.build").source_hash()
+        pmc, pmc_meta = load_pmc(args.workload, src_hash) if (world == 1 and standard) else (None, {"file": None, "why": "counters are per frame of the standard single-GPU workload"})
         classes = {
-            "traversal": class_roofline("traversal", xst.ms_extend + xst.ms_connect, xst.extend_launches + xst.connect_launches,
-                                        (tot["ms_extend"] + tot["ms_connect"]) / steps, (tot["extend_launches"] + tot["connect_launches"]) / steps, pmc,
-                                        algorithmic_bytes=xst.rays * b_ray),
-            "shade": class_roofline("shade", xst.ms_shade_kernels, xst.shade_launches, tot["ms_shade_kernels"] / steps, tot["shade_launches"] / steps, pmc),
+            "traversal": class_roofline("traversal", xst.ms_extend + xst.ms_connect, xst.extend_launches + xst.connect_launches, pmc, algorithmic_bytes=xst.rays * b_ray),
+            "shade": class_roofline("shade", xst.ms_shade_kernels, xst.shade_launches, pmc),
         }
         dom = max(classes, key=lambda k: classes[k]["ms_per_frame_single_lane"])
         d = classes[dom]
-        have = d.get("valu_lane_frac") is not None
+        ceiling = None
+        if os.path.exists(CEILING_FILE):
+            cj = json.load(open(CEILING_FILE))
+            pick = lambda inst: max((r["per_cycle_per_simd"] for r in cj["rows"] if r["inst"] == inst and r["chains"].startswith("8")), default=None)
+            ceiling = {"file": os.path.relpath(CEILING_FILE, ROOT), "per_cycle_per_simd": {k: pick(k) for k in ("v_fma_f32", "v_mul_f32", "v_add_f32", "v_max_f32", "v_cndmask_b32_e64 (mask in an SGPR pair)", "v_cmp_lt_f32_e64 -> SGPR pair", "v_fma_f64")},
+                       "what": "measured wave64 issue rates on MI355X (tools/valu_ceiling.hip): fp32 add / mul / fma ~0.45 per cycle and SIMD, comparison / select / min-max class ~0.24; a mix of both classes issues side by side"}
         roof = {
-            "kernel": "%s kernels (%s)" % (dom, ", ".join(d["counters"]["kernels"]) if d.get("counters") else ("k_extend_rf + k_connect[_rf]" if dom == "traversal" else "k_shade<material, features>")),
-            "bound": "valu-issue",
-            "why": "divergent, latency-exposed scalar code: neither class moves more than a fraction of the HBM peak (hbm_counter_frac) and the tree / path state it reads is served by LDS and L2; what is scarce is VALU issue slots with lanes in them",
-            "achieved": d.get("valu_tlaneops"), "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s (active-lane VALU instructions; peak = 1 wave64 instruction / 2 cycles / SIMD at 2.4 GHz = the 157 TFLOP/s fp32 vector peak)",
-            "frac": d.get("valu_lane_frac"),
-            "valu_pipe_busy_frac_profiled": d.get("valu_pipe_busy_frac_profiled"),  # the VALU pipes are busy this share of the time; `frac` is lower by the idle lanes and the 4-cycle plain-fp32 issue
+            "kernel": "%s kernels (%s)" % (dom, ", ".join(d["counters"]["kernels"]) if d.get("counters") else ("k_extend_rf + k_connect_rf" if dom == "traversal" else "k_shade<material, features>")),
+            "bound": d.get("bound"),
+            "why": "neither class moves more than a fraction of the HBM peak (hbm.frac); the scarce resource is vector issue: `frac` is the share of the SIMDs' vector-ALU time the class's instructions need at the measured gfx950 issue rates (valu_ceiling), the rest of a wave's time is s_waitcnt (wave_wait_frac) with too few resident waves to cover it",
+            "achieved": d.get("valu_ginst_per_s"), "peak": d.get("valu_ceiling_ginst_per_s"), "unit": "G wave64 VALU instructions/s (peak = what 1024 SIMDs issue of this class's instruction mix at the measured rates)",
+            "frac": d.get("valu_pipe_frac"), "frac_lo_hi": d.get("valu_pipe_frac_lo_hi"),
+            "wave": {"issue": d.get("wave_issue_frac"), "wait": d.get("wave_wait_frac"), "stall": d.get("wave_stall_frac"), "salu_per_valu": d.get("salu_per_valu"), "lanes_per_valu_inst": d.get("lanes_per_valu_inst"),
+                     "lds_busy": d.get("lds_busy_frac"), "lds_conflict_share": d.get("lds_conflict_share")},
             "traffic": d.get("hbm_bytes_per_launch"),
             "hbm": {"achieved": d.get("hbm_counter_gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d.get("hbm_counter_frac"), "what": "FETCH_SIZE + WRITE_SIZE of the class's kernels (committed rocprofv3 PMC passes) / their single-lane duration measured in this run"},
             "algorithmic": {"what": "SURVEY 8(d): 32 B ray in + 32 B per box tested + 48 B per triangle tested + 16 B hit out, x rays / traversal-kernel time; NOT HBM traffic (LDS- and L2-served)",
-                            "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray, "gbs": classes["traversal"].get("algorithmic_gbs"), "frac_of_hbm_peak": classes["traversal"].get("algorithmic_frac"),
+                            "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray, "gbs": classes["traversal"].get("algorithmic_gbs"), "frac_of_hbm_peak": classes["traversal"].get("algorithmic_frac_of_hbm_peak"),
                             "bytes_per_launch": xst.rays * b_ray / max(xst.extend_launches + xst.connect_launches, 1)},
-            "classes": classes,
-            "counters_from": (os.path.relpath(PMC_FILE % args.workload, ROOT) if pmc is not None else None), "counters_meta": pmc_meta,
-            "counters_usable": bool(have),
-            "timing": "HIP events around every launch on the lanes' own streams; fractions use the single-lane frame (ms_per_frame_single_lane), the timed steps overlap passes on %d pipeline lanes" % lanes,
+            "classes": classes, "valu_ceiling": ceiling,
+            "counters_from": pmc_meta, "counters_usable": bool(d.get("valu_pipe_frac") is not None),
+            "timing": "HIP events around every launch of ONE untimed frame on a single pipeline lane (ms_per_frame_single_lane); the timed steps run the default path on %d lanes without events" % lanes,
             "single_lane_frame_ms": {"extend": xst.ms_extend, "connect": xst.ms_connect, "shade": xst.ms_shade_kernels, "aux (generate, epilogue, resolve)": xst.ms_aux, "film": xst.ms_film},
-            "b_state_bytes_per_path_round": 224, "hbm_copy_measured_gbs": hbm_copy_gbs(torch, dev),
+            "b_state_bytes_per_path_round": 216, "hbm_copy_measured_gbs": hbm_copy_gbs(torch, dev),
         }
         # film check: rows of the timed film against the committed oracle fixture
         film_check = "no fixture for these settings"
@@ -378,16 +511,23 @@ def main():
             "dtype": "f32", "data": "synthetic (%s, deterministic Sobol sequence)" % ("data/cornell-box.xml as parsed" if args.workload == "cornell" else "procedural %s scene, seeded" % args.workload),
             "config": {"workload": wl["label"] % (W, H, spp, args.depth),
                        "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world,
-                       "band_plan": ("single band" if world == 1 else ("equal height" if bounds is None else "equal cost (1-spp probe in 64 strips, %.0f ms, untimed setup): rows %s" % (probe_ms, bounds))),
+                       "band_plan": ("single band" if world == 1 else ("equal height" if bounds is None else "equal cost (1-spp probe in 64 strips): rows %s" % (bounds,))),
+                       "band_probe_ms": probe_ms, "value_incl_band_probe": rays / (dt + args.steps * probe_ms * 1e-3) / 1e6,  # a host that plans its bands per frame pays the probe per frame
                        "collective": ("none" if world == 1 else ("rccl gather of film row bands" if backend == "nccl" else backend + " gather (host-staged fallback, NOT an RCCL number)")),
                        "halo_overhead": rows_traced / float(H + 4) - 1.0, "rays_traced_incl_halo_per_step": rays_traced / args.steps,
-                       "pipeline_lanes": lanes},
+                       "pipeline_lanes": lanes, "timed_path": "library default (no PTRS_FLAG_TIMING)",
+                       "launch": {"queue_segments_per_pass": st.queue_segments, "passes_per_frame": st.passes, "kernel_launches_per_frame": st.kernel_launches,
+                                  "workgroups_last_launch": dict(zip(("extend", "connect", "shade", "aux"), [int(x) for x in st.grid_wgs])),
+                                  "resident_workgroups_per_cu": dict(zip(("extend", "connect", "shade", "aux"), [int(x) for x in st.resident_wgs_per_cu])),
+                                  "options": {k: pkg.get_option(k) for k in ("lanes", "grid_mult", "grid_pct", "persist", "refill", "refill_connect", "vote")}}},
             "roofline": roof,
             "film_check": film_check, "film_check_rel_l2": roof_rel,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cornell" and standard:
             gpu_rows = film[500:628].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(pkg, gpu_rows)
+        if world == 1 and not args.no_collective_smoke:
+            out["collective_smoke"] = collective_smoke()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PTRS_ABI_VERSION 2
+#define PTRS_ABI_VERSION 3
 
 enum {
     PTRS_OK = 0,
@@ -171,7 +171,8 @@ enum { PTRS_SAMPLER_SOBOL = 0, PTRS_SAMPLER_STRATIFIED = 1 };
 
 enum {
     PTRS_FLAG_COUNTERS = 1u, /* fill nodes_visited / tris_tested (slower: device atomics) */
-    PTRS_FLAG_TIMING = 2u    /* hipEvent timing of every kernel launch (needs stream syncs) */
+    PTRS_FLAG_TIMING = 2u,   /* hipEvent timing of every kernel launch (needs stream syncs) */
+    PTRS_FLAG_FILM_ZERO = 4u /* ptrs_render_multi: film_inout is all zeros (Film::clear), the devices clear their bands instead of uploading them */
 };
 
 /* film pixel: linear RGB sums and filter-weight sum (film.rs:113-119; splat_xyz is never
@@ -210,6 +211,12 @@ typedef struct PtrsStats {
      * node_visits / node_steps_x64 and tris_tested (of these kernels) / tri_steps_x64 */
     uint64_t node_steps_x64, node_visits, tri_steps_x64;
     uint64_t debug[12];      /* zero in product builds; diagnostic builds (-DPTRS_STAMPS): wave-clock sums per phase of k_shade */
+    /* how the queue kernels of the call's last pass were launched (ABI 3): segments per queue (one wave each), and per kernel class
+     * [0] extend, [1] connect, [2] shade, [3] aux the workgroups of the last launch and the resident workgroups per CU the launch was
+     * sized for (hipOccupancyMaxActiveBlocksPerMultiprocessor) */
+    uint64_t queue_segments;
+    uint64_t grid_wgs[4];
+    uint64_t resident_wgs_per_cu[4];
 } PtrsStats;
 
 enum {
@@ -232,6 +239,9 @@ typedef struct PtrsScene PtrsScene;
  * Replaces nothing in the reference (its only knobs are the CLI flags of main.rs:36-52). */
 int ptrs_set_option(const char *name, int64_t value);
 int ptrs_get_option(const char *name, int64_t *value);
+/* The same knobs for ONE scene: its renders take this value instead of the process-wide one (two embedders in a process, or
+ * two scenes of one embedder, can differ).  Knobs read at scene creation (node_form, stack_lds) are not affected. */
+int ptrs_scene_set_option(PtrsScene *scene, const char *name, int64_t value);
 
 int ptrs_abi_version(void);
 int ptrs_abi_sizeof(int which); /* sizeof the ABI structs as compiled (binding self-check) */
@@ -302,6 +312,16 @@ typedef struct PtrsHit {
 } PtrsHit;
 int ptrs_trace_rays(PtrsScene *scene, uint32_t n, const float *rays, int32_t any_hit,
                     PtrsHit *hits_out, PtrsStats *stats);
+
+/* Traversal bench (the reference's precedent: benches/benchmark_pathtracer.rs:35-54, scene.intersect on one ray in a loop).
+ * ptrs_render_dump_rays: starts `params`' render, stops in its first pass before round `round` and returns that round's extension
+ * rays (round 0: the camera rays, round k: the rays leaving the paths' k-th vertices), at most max_rays records of 7 floats.
+ * ptrs_trace_bench: closest-hit traversal of n rays with the frame's own extension kernel (lane refill, phase voting, persistent
+ * waves), `repeats` timed launches after one counting launch: stats->ms_trace (sum of the timed launches), nodes_visited /
+ * tris_tested (of ONE launch), rays_extension = n * repeats; hits_out (NULL or n records, t not filled) equals ptrs_trace_rays'. */
+int ptrs_render_dump_rays(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, uint32_t round,
+                          uint32_t max_rays, float *rays_out, uint32_t *n_out);
+int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t repeats, PtrsHit *hits_out, PtrsStats *stats);
 
 /* SobolSampler (sampler/sobol.rs): value of dimension dims[i] for sample sample_nums[i] of pixel
  * (px[i],py[i]) with the sampler built for `params` -- the device implementation of

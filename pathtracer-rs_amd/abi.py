@@ -12,7 +12,7 @@ TEX_CONSTANT, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
 MAT_MATTE, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_DISNEY, MAT_SUBSTRATE, MAT_NORMAL = range(7)
 LIGHT_POINT, LIGHT_DIRECTIONAL, LIGHT_AREA, LIGHT_INFINITE = range(4)
-FLAG_COUNTERS, FLAG_TIMING = 1, 2
+FLAG_COUNTERS, FLAG_TIMING, FLAG_FILM_ZERO = 1, 2, 4
 SAMPLER_SOBOL, SAMPLER_STRATIFIED = 0, 1
 
 f32p = C.POINTER(C.c_float)
@@ -76,7 +76,8 @@ class PtrsStats(C.Structure):
                 ("ms_extend", C.c_double), ("ms_connect", C.c_double), ("ms_shade_kernels", C.c_double), ("ms_aux", C.c_double),
                 ("extend_launches", C.c_uint64), ("connect_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("aux_launches", C.c_uint64),
                 ("film_launches", C.c_uint64), ("error_flags", C.c_uint64), ("node_steps_x64", C.c_uint64), ("node_visits", C.c_uint64),
-                ("tri_steps_x64", C.c_uint64), ("debug", C.c_uint64 * 12)]
+                ("tri_steps_x64", C.c_uint64), ("debug", C.c_uint64 * 12), ("queue_segments", C.c_uint64), ("grid_wgs", C.c_uint64 * 4),
+                ("resident_wgs_per_cu", C.c_uint64 * 4)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -36,6 +36,18 @@ def sources():
         os.path.join(ROOT, "include", "ptrs.h"), os.path.join(ROOT, "include", "ptrs_detmath.h")]
 
 
+def source_hash():
+    """sha256 over what determines the kernels: every file of csrc/, the two headers, the compiler flags.  Counter summaries under
+    profiles/ carry it, and bench.py uses a summary only when it equals the hash of the tree it runs from."""
+    import hashlib
+    _gen_tables_inc()
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for s in sources():
+        h.update(os.path.basename(s).encode())
+        h.update(open(s, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, extra_flags=(), verbose=False):
     _gen_tables_inc()
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in sources()):

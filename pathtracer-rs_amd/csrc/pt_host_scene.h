@@ -121,7 +121,11 @@ struct Builder {
 } // namespace hostbvh
 
 // node_form: 0 = by size (pair nodes when the tree fits the LDS staging area, quad nodes otherwise), 1 = pair, 2 = quad (test hook)
-inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &err, int node_form = 0) {
+// node_order (quad form): 0 = the tree's top QUAD_TOP_NODES records breadth-first (what the traversal kernels cache in LDS), the rest in the
+// builder's depth-first order; 1 = treelets: behind the top, every subtree of three quad levels (1 + 4 + 16 records = 2.7 KB) sits in
+// consecutive records, so that a ray's next two fetches after entering a treelet fall into lines its neighbours in the wave are
+// fetching too.  An order, not a different tree: same visits, same results.
+inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &err, int node_form = 0, int node_order = 0) {
     auto bad = [&](const char *m) { err = m; return (int)PTRS_ERR_INVALID; };
     if (d.n_meshes && !d.meshes) return bad("meshes is NULL");
     // ---- textures -------------------------------------------------------------------------------
@@ -467,15 +471,35 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
     if (H.use_quad && H.nodes4.size() > QUAD_TOP_NODES) {
         // breadth-first order for the top of the tree: the first QUAD_TOP_NODES records are the ones every ray starts in,
         // and the traversal kernels keep them in LDS
-        std::vector<uint32_t> newid(H.nodes4.size(), 0xffffffffu), bfs; bfs.reserve(QUAD_TOP_NODES);
-        bfs.push_back(0);
-        for (size_t h = 0; h < bfs.size() && bfs.size() < QUAD_TOP_NODES; ++h)
-            for (int sl = 0; sl < 4 && bfs.size() < QUAD_TOP_NODES; ++sl) { const uint32_t r = H.nodes4[bfs[h]].ref[sl]; if (r != REF_NONE && !(r & REF_LEAF)) bfs.push_back(r); }
+        std::vector<uint32_t> newid(H.nodes4.size(), 0xffffffffu), seq; seq.reserve(H.nodes4.size());
+        auto kids = [&](uint32_t o, std::vector<uint32_t> &out) { for (int sl = 0; sl < 4; ++sl) { const uint32_t r = H.nodes4[o].ref[sl]; if (r != REF_NONE && !(r & REF_LEAF)) out.push_back(r); } };
+        std::vector<uint32_t> roots; // subtrees still to be laid out
+        {
+            std::vector<uint32_t> bfs; bfs.push_back(0);
+            for (size_t h = 0; h < bfs.size() && bfs.size() < QUAD_TOP_NODES; ++h) { std::vector<uint32_t> k; kids(bfs[h], k); for (uint32_t r : k) { if (bfs.size() < QUAD_TOP_NODES) bfs.push_back(r); else roots.push_back(r); } }
+            // children of the top's own last records that were never expanded
+            std::vector<char> in_top(H.nodes4.size(), 0); for (uint32_t o : bfs) in_top[o] = 1;
+            roots.clear();
+            for (uint32_t o : bfs) { std::vector<uint32_t> k; kids(o, k); for (uint32_t r : k) if (!in_top[r]) roots.push_back(r); }
+            seq = bfs;
+        }
+        if (node_order == 1) {
+            // treelets of three levels, each laid out breadth-first, in the order their roots were met
+            for (size_t h = 0; h < roots.size(); ++h) {
+                std::vector<uint32_t> level{roots[h]};
+                for (int l = 0; l < 3 && !level.empty(); ++l) {
+                    std::vector<uint32_t> next;
+                    for (uint32_t o : level) { seq.push_back(o); kids(o, next); }
+                    level.swap(next);
+                }
+                for (uint32_t o : level) roots.push_back(o); // the records below the treelet's third level start treelets of their own
+            }
+        }
         uint32_t next = 0;
-        for (uint32_t o : bfs) newid[o] = next++;
+        for (uint32_t o : seq) newid[o] = next++;
         for (size_t o = 0; o < H.nodes4.size(); ++o) if (newid[o] == 0xffffffffu) newid[o] = next++;
         std::vector<DNode4> re(H.nodes4.size());
-        for (size_t o = 0; o < H.nodes4.size(); ++o) { DNode4 d = H.nodes4[o]; for (int sl = 0; sl < 4; ++sl) if (d.ref[sl] != REF_NONE && !(d.ref[sl] & REF_LEAF)) d.ref[sl] = newid[d.ref[sl]]; re[newid[o]] = d; }
+        for (size_t o = 0; o < H.nodes4.size(); ++o) { DNode4 dn = H.nodes4[o]; for (int sl = 0; sl < 4; ++sl) if (dn.ref[sl] != REF_NONE && !(dn.ref[sl] & REF_LEAF)) dn.ref[sl] = newid[dn.ref[sl]]; re[newid[o]] = dn; }
         H.nodes4.swap(re);
     }
     H.tris.resize(order.size());

@@ -140,11 +140,15 @@ inline void plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_
 }
 
 struct RenderProgress { void (*fn)(void *user, uint32_t done, uint32_t total, int32_t row_begin, int32_t row_end); void *user; };
+// ptrs_render_dump_rays: the render stops in its first pass before round `round` and hands out the extension rays of that round
+// (round 0: the camera rays; round k: the rays leaving the paths' k-th vertices) -- ray sets of a real frame for the traversal bench.
+struct RayDump { uint32_t round, max_rays; float *out /* backend memory, max_rays x 7: o, d, t_max */; uint32_t *n_out /* host */; };
 
 template <class BE>
 int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_t bvh_depth, const PtrsCamera &cam, const PtrsRenderParams &prm,
                 v4 *film /* backend memory, W*H */, float *samples_out /* backend memory or null */, PtrsStats *stats, std::string &err,
                 const RenderProgress *progress = nullptr /* called after every pass with the rows it touched (back end copies them out first) */,
+                const RayDump *dump = nullptr,
                 const int32_t *single_pixel = nullptr /* render_single_pixel (integrator.rs:505-534): raster (px, py), any pixel of the sample bounds;
                                                          traces that pixel's spp paths only, no film, samples_out = spp * 3 floats */) {
     using clock = std::chrono::steady_clock;
@@ -303,6 +307,13 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             be.pass_begin(R);
             be.generate();
             uint32_t it = 0;
+            if (dump) { // (test / bench hook: nothing is rendered beyond the rounds before the dump)
+                for (; it < dump->round && it < max_iters; ++it) round(it);
+                be.dump_rays(it, *dump);
+                be.end(st);
+                if (stats) *stats = st;
+                return PTRS_OK;
+            }
             for (; it < std::min(fixed_iters + spare_rounds, max_iters); ++it) round(it);
             // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
             const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);

@@ -44,12 +44,14 @@ struct Options {
     int grid_pct = 100;       // share of its resident capacity a persistent launch takes: below 100 a kernel leaves wave slots to the kernels of the other pipeline lanes
     int persist = 1;          // queue kernels are launched with the workgroups that fit the machine at once (occupancy x CUs); 0: with 8 per CU, the hardware's maximum (A/B hook)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
+    int node_order = 0;       // quad form, records behind the LDS-cached top: 0 = the builder's depth-first order, 1 = treelets of three levels (pt_host_scene.h)
     int vote = -1;            // lane-refill traversal kernels: each step runs the phase (node visit / triangle test) most lanes of the wave are in.
                               // 0 off, 1 both kernels, 2 extension kernel only, -1 = by scene: 1 for quad-form scenes (colonnade extend 86 -> 56 ms), 2 for the LDS-resident
                               // pair form, whose cheap steps do not pay for the vote in the connect kernel (Cornell: extend 92.5 -> 89 ms, connect 52 -> 63 ms)
     int fused_epilogue = 1;   // k_extend_rf / k_connect_rf run their segment's epilogue (emission, depth cut, material bucketing) / MIS resolve behind their last ray; 0: the separate k_epilogue / k_resolve
     int fused_resolve = 1;    // (with fused_epilogue) k_connect_rf resolves its MIS records itself
     int shade_lds = 1;        // shade kernels read light records, small scenes' triangle records and the round's Sobol' tables from LDS (0: everything from global memory)
+    int peer_copy = 1;        // ptrs_render_multi: bands travel device to device (hipMemcpyPeerAsync over xGMI); 0: staged through the host film, the path taken when two devices cannot reach each other (test hook)
     int workspace_pct = 40;   // the render workspace (path state + queues of all lanes) may take this share of the device memory that is free at the call
 };
 Options g_opt;
@@ -58,7 +60,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"grid_pct", &Options::grid_pct, 10, 100}, {"node_form", &Options::node_form, 0, 2}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90},
+    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"grid_pct", &Options::grid_pct, 10, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -417,7 +419,10 @@ __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQu
 // registers (5 waves), and a few registers more cost a wave and 4 % of the kernel's time (colonnade k_connect_rf: 92 -> 101
 // registers, 36.7 -> 38.2 ms): the hint pins them at 5, the small LDS-resident pair form at 6 (74-80 registers).  The others
 // are left to the compiler (0 = no hint): LDS holds them at 4 waves anyway, or the full feature set needs 110-120 registers.
-template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? 6 : ((GEOM == 0 && DEPTH == 8 && FEAT == FEAT_SIMPLE) ? 5 : 0) }; };
+#ifndef PTRS_LDS_WAVES
+#define PTRS_LDS_WAVES 6
+#endif
+template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? PTRS_LDS_WAVES : ((GEOM == 0 && DEPTH == 8 && FEAT == FEAT_SIMPLE) ? 5 : 0) }; };
 template <int DEPTH, int GEOM> struct TravLds { enum { TOP = GEOM == 0 && DEPTH == 8, V4 = GEOM > 0 ? GEOM : (TOP ? TOP_LDS_STRIDE * QUAD_TOP_NODES : 1) }; }; // quad form with the small stack column: the tree's top lives in LDS
 
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
@@ -866,6 +871,26 @@ __global__ __launch_bounds__(64) void k_strat_tables(int32_t NX, int32_t NY, uin
     stratified_tile_tables((uint64_t)(ty * ntx + tx), tx * 16, min(tx * 16 + 16, NX), ty * 16, min(ty * 16 + 16, NY), NX, dim_ps, n_dims, tab1, tab2);
 }
 
+// The extension rays of round `it` as (o, d, +inf) records, whole 64-entry blocks of a segment together (the order a traversal wave meets them in)
+__global__ __launch_bounds__(BLOCK) void k_dump_rays(DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t G, uint32_t max_rays, float *out, uint32_t *n_out) {
+    const uint32_t lane = threadIdx.x & 63u, s = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (s >= G) return;
+    const uint32_t *queue = Q.ext[it & 1u] + (size_t)s * seg_cap;
+    const uint32_t n = *seg_count(Q, it, Q_EXT, G, s);
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const uint32_t i = i0 + lane, cnt = n - i0 < 64u ? n - i0 : 64u;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(n_out, cnt);
+        base = rfl(base);
+        if (i < n && base + lane < max_rays) {
+            const uint32_t pid = queue[i];
+            const v4 o = P.ray_o[pid], d = P.ray_d[pid];
+            float *r = out + (size_t)(base + lane) * 7u;
+            r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = PT_INF;
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_export_samples(DParams R, DSampler S, DPaths P, float *out) {
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < R.n_paths; pid += stride) {
@@ -964,6 +989,7 @@ struct PtrsScene {
     DevBuf stack_spill;  // global part of the traversal stacks (trees deeper than the LDS column), one column per resident thread
     StackSpill spill{nullptr, 0};
     size_t spill_lane_elems = 0;
+    std::map<std::string, int> overrides;  // ptrs_scene_set_option: this scene's renders take these instead of the process-wide values
     std::map<const void *, int> occupancy; // workgroups per CU by kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor), asked once
     uint32_t stack_lds = 16; // LDS stack entries per lane: 8 when the tree allows it, else 16 (+ spill)
     // render workspace, grown on demand and reused across calls
@@ -1061,7 +1087,7 @@ struct HipBackend {
     // Workgroups of a persistent queue kernel: what fits the machine at once (the kernel's resident workgroups per CU x CUs), never
     // more than the segments need (4 waves = 4 segments per workgroup).  A launch that over-estimates the residency loses nothing:
     // workgroups that start late find the ticket counter exhausted and leave.
-    uint32_t resident_wgs[T_NUM] = {0, 0, 0, 0, 0}; // last launch of each class (PtrsStats)
+    uint32_t last_grid[T_NUM] = {0, 0, 0, 0, 0}, last_per_cu[T_NUM] = {0, 0, 0, 0, 0}; // last launch of each class (PtrsStats)
     template <class F> uint32_t persistent_grid(F fn, int cat) {
         const void *key = reinterpret_cast<const void *>(fn);
         auto itr = ps->occupancy.find(key);
@@ -1074,8 +1100,8 @@ struct HipBackend {
         } else per_cu = itr->second;
         if (!opt.persist) per_cu = 8;
         const uint32_t need = (G + WAVES - 1) / WAVES, fit = std::max(1u, (uint32_t)ps->n_cu * (uint32_t)per_cu * (uint32_t)opt.grid_pct / 100u);
-        resident_wgs[cat] = fit;
-        return need < fit ? need : fit;
+        last_grid[cat] = need < fit ? need : fit; last_per_cu[cat] = (uint32_t)per_cu;
+        return last_grid[cat];
     }
     uint32_t *ticket(uint32_t it, int which) { return Q.tickets + ((size_t)it * Q_STRIDE + (size_t)which) * TK_LAUNCH_WORDS; }
 
@@ -1231,7 +1257,18 @@ struct HipBackend {
     void publish_rows(v4 *film_px, int32_t y0, int32_t y1) {
         if (!host_film || hipStreamSynchronize(stream) != hipSuccess) { rc = host_film ? PTRS_ERR_DEVICE : rc; return; }
         const size_t off = (size_t)y0 * (size_t)film_w, cnt = (size_t)(y1 - y0) * (size_t)film_w;
-        if (hipMemcpy(host_film + off, film_px + off, cnt * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost) != hipSuccess) rc = PTRS_ERR_DEVICE;
+        // (on the lane's own stream: a blocking copy on the legacy null stream would also wait for whatever lane 0 has queued behind this pass)
+        if (hipMemcpyAsync(host_film + off, film_px + off, cnt * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE;
+    }
+    void dump_rays(uint32_t it, const RayDump &d) {
+        DevBuf cnt;
+        if (cnt.ensure(16) != PTRS_OK) { rc = PTRS_ERR_DEVICE; return; }
+        (void)hipMemsetAsync(cnt.p, 0, 16, stream);
+        hipLaunchKernelGGL(k_dump_rays, dim3((G + WAVES - 1) / WAVES), dim3(BLOCK), 0, stream, P, Q, it, seg_cap, G, d.max_rays, d.out, (uint32_t *)cnt.p);
+        uint32_t n = 0;
+        if (hipMemcpyAsync(&n, cnt.p, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = PTRS_ERR_DEVICE;
+        *d.n_out = n < d.max_rays ? n : d.max_rays;
+        cnt.release();
     }
     void export_samples(float *out) { t0(T_FILM); hipLaunchKernelGGL(k_export_samples, dim3(grid_for(R.n_paths)), dim3(BLOCK), 0, stream, R, S, P, out); t1(); }
     void end(PtrsStats &st) {
@@ -1251,6 +1288,8 @@ struct HipBackend {
             }
         }
         st.ms_trace = st.ms_extend + st.ms_connect; st.ms_shade = st.ms_shade_kernels + st.ms_aux;
+        st.queue_segments = G;
+        { const int cls[4] = {T_EXTEND, T_CONNECT, T_SHADE, T_AUX}; for (int k = 0; k < 4; ++k) { st.grid_wgs[k] = last_grid[cls[k]]; st.resident_wgs_per_cu[k] = last_per_cu[cls[k]]; } }
         st.extend_launches = cat_launches[T_EXTEND]; st.connect_launches = cat_launches[T_CONNECT]; st.shade_launches = cat_launches[T_SHADE]; st.aux_launches = cat_launches[T_AUX]; st.film_launches = cat_launches[T_FILM];
         size_t bytes = 0;
         for (auto &l : ps->ws) for (auto &b : l) bytes += b.bytes;
@@ -1259,16 +1298,22 @@ struct HipBackend {
     }
 };
 
+Options scene_options(const PtrsScene *ps) { // the process-wide knobs with this scene's overrides on top
+    Options o = options();
+    for (const OptionDesc &d : k_options) { auto it = ps->overrides.find(d.name); if (it != ps->overrides.end()) o.*(d.field) = it->second; }
+    return o;
+}
+
 int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm, v4 *film_dev, float *samples_dev, hipStream_t stream, PtrsStats *stats, const int32_t *single_pixel = nullptr,
-              const RenderProgress *progress = nullptr, PtrsFilmPixel *host_film = nullptr) {
+              const RenderProgress *progress = nullptr, PtrsFilmPixel *host_film = nullptr, int share = 1, const RayDump *dump = nullptr) {
     if (!ps || !cam || !prm || (!film_dev && !single_pixel)) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     HIPCHK(hipSetDevice(ps->device));
     HipBackend be;
-    be.ps = ps; be.stream = stream; be.opt = options(); be.host_film = host_film; be.film_w = prm->width;
+    be.ps = ps; be.stream = stream; be.opt = scene_options(ps); be.host_film = host_film; be.film_w = prm->width; be.share = share;
     int rc = get_sobol(ps->device, &be.sob);
     if (rc != PTRS_OK) return rc;
     std::string err;
-    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err, progress, single_pixel);
+    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err, progress, dump, single_pixel);
     if (rc != PTRS_OK) { if (!err.empty()) g_err = err; return rc; }
     if (be.rc != PTRS_OK) { if (g_err.empty()) g_err = "device error during render"; return be.rc; }
     return PTRS_OK;
@@ -1332,7 +1377,7 @@ static int scene_create_impl(const PtrsSceneDesc *desc, int32_t device, PtrsScen
     PtrsScene *ps = new PtrsScene();
     ps->device = device;
     const Options opt = options();
-    int rc = build_host_scene(*desc, ps->H, g_err, opt.node_form);
+    int rc = build_host_scene(*desc, ps->H, g_err, opt.node_form, opt.node_order);
     if (rc != PTRS_OK) { delete ps; return rc; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ps->n_cu = prop.multiProcessorCount;
@@ -1442,59 +1487,97 @@ int ptrs_plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_t *
     return guarded([&]() -> int { plan_bands(height, n, row_cost, bounds_out); return PTRS_OK; });
 }
 
+int ptrs_scene_set_option(PtrsScene *scene, const char *name, int64_t value) {
+    if (!scene || !name) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+    for (const OptionDesc &o : k_options)
+        if (!std::strcmp(name, o.name)) {
+            if (value < o.lo || value > o.hi) { g_err = std::string("option ") + name + ": value outside [" + std::to_string(o.lo) + ", " + std::to_string(o.hi) + "]"; return PTRS_ERR_INVALID; }
+            return guarded([&]() -> int { scene->overrides[name] = (int)value; return PTRS_OK; });
+        }
+    g_err = std::string("unknown option ") + name;
+    return PTRS_ERR_INVALID;
+}
+
 int ptrs_render_multi(PtrsScene *const *scenes, uint32_t n, const PtrsCamera *camera, const PtrsRenderParams *params, const int32_t *band_bounds,
                       PtrsFilmPixel *film_inout, PtrsStats *stats_per_scene) {
     return guarded([&]() -> int {
         if (!scenes || n == 0 || !camera || !params || !film_inout) { g_err = "null argument"; return PTRS_ERR_INVALID; }
-        for (uint32_t i = 0; i < n; ++i) if (!scenes[i]) { g_err = "null scene"; return PTRS_ERR_INVALID; }
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!scenes[i]) { g_err = "null scene"; return PTRS_ERR_INVALID; }
+            for (uint32_t j = 0; j < i; ++j) if (scenes[j] == scenes[i]) { g_err = "the same scene handle twice: every band needs a scene (workspace, film) of its own"; return PTRS_ERR_INVALID; }
+        }
         const int32_t H = params->height, W = params->width;
         std::vector<int32_t> bounds(n + 1);
         if (band_bounds) { bounds.assign(band_bounds, band_bounds + n + 1); }
         else plan_bands(H, n, nullptr, bounds.data());
         if (bounds[0] != 0 || bounds[n] != H) { g_err = "band bounds must run from 0 to height"; return PTRS_ERR_INVALID; }
         for (uint32_t i = 0; i < n; ++i) if (bounds[i + 1] < bounds[i]) { g_err = "band bounds must not decrease"; return PTRS_ERR_INVALID; }
-        // Each device renders its band into a film of its own; the bands are then gathered into device 0's film with peer
-        // copies over xGMI (hipMemcpyPeer; staged through the host where two devices cannot reach each other) and leave
-        // through one device-to-host copy.  Rows are disjoint and every sample's value depends only on (pixel, sample
-        // index), so the result is bit-identical to ptrs_render on one device.
+        // Each device renders its band into a band-sized film of its own and, as soon as its render is through, pushes the band into
+        // device 0's film over xGMI (hipMemcpyPeerAsync on a stream of its own; staged through the host film where two devices cannot
+        // reach each other): no device waits for another, the gather overlaps the slower devices' renders.  Device 0's film leaves
+        // through one device-to-host copy.  Rows are disjoint and every sample's value depends only on (pixel, sample index), so the
+        // result is bit-identical to ptrs_render on one device.
         const size_t npx = (size_t)W * (size_t)H;
-        std::vector<int> rcs(n, PTRS_OK); std::vector<std::string> errs(n);
-        std::vector<std::thread> th;
-        for (uint32_t i = 0; i < n; ++i) {
-            th.emplace_back([&, i]() {
-                PtrsScene *ps = scenes[i];
-                rcs[i] = guarded([&]() -> int {
-                    if (bounds[i + 1] == bounds[i]) { if (stats_per_scene) std::memset(&stats_per_scene[i], 0, sizeof(PtrsStats)); return PTRS_OK; }
-                    HIPCHK(hipSetDevice(ps->device));
-                    int rc = ps->film_tmp.ensure(npx * sizeof(PtrsFilmPixel));
-                    if (rc != PTRS_OK) return rc;
-                    const size_t off = (size_t)bounds[i] * W, cnt = (size_t)(bounds[i + 1] - bounds[i]) * W;
-                    HIPCHK(hipMemcpy((PtrsFilmPixel *)ps->film_tmp.p + off, film_inout + off, cnt * sizeof(PtrsFilmPixel), hipMemcpyHostToDevice));
-                    PtrsRenderParams p = *params;
-                    p.row_begin = bounds[i]; p.row_end = bounds[i + 1]; p.device = ps->device;
-                    return do_render(ps, camera, &p, (v4 *)ps->film_tmp.p, nullptr, nullptr, stats_per_scene ? &stats_per_scene[i] : nullptr);
-                });
-                if (rcs[i] != PTRS_OK) errs[i] = g_err; // thread-local message of the worker
-            });
-        }
-        for (auto &t : th) t.join();
-        for (uint32_t i = 0; i < n; ++i) if (rcs[i] != PTRS_OK) { g_err = "device " + std::to_string(scenes[i]->device) + ": " + errs[i]; return rcs[i]; }
         PtrsScene *root = scenes[0];
         HIPCHK(hipSetDevice(root->device));
         int rc = root->film_tmp.ensure(npx * sizeof(PtrsFilmPixel));
         if (rc != PTRS_OK) return rc;
-        for (uint32_t i = 1; i < n; ++i) {
+        const bool film_is_zero = (params->flags & PTRS_FLAG_FILM_ZERO) != 0; // the caller vouches for a cleared film: nothing to upload
+        std::vector<int> share(n, 0);
+        for (uint32_t i = 0; i < n; ++i) for (uint32_t j = 0; j < n; ++j) if (scenes[j]->device == scenes[i]->device && bounds[j + 1] > bounds[j]) ++share[i]; // renders dividing one device's memory
+        std::vector<int> rcs(n, PTRS_OK); std::vector<std::string> errs(n);
+        std::vector<char> staged(n, 0); // band i travelled through film_inout (no peer path): it is copied into the root film after the join
+        auto work = [&](uint32_t i) {
+            PtrsScene *ps = scenes[i];
+            rcs[i] = guarded([&]() -> int {
+                if (stats_per_scene) std::memset(&stats_per_scene[i], 0, sizeof(PtrsStats));
+                if (bounds[i + 1] == bounds[i]) return PTRS_OK;
+                HIPCHK(hipSetDevice(ps->device));
+                const size_t off = (size_t)bounds[i] * W, cnt = (size_t)(bounds[i + 1] - bounds[i]) * W, bytes = cnt * sizeof(PtrsFilmPixel);
+                // the band's rows only; the render addresses the film by absolute row, so it gets the band's base moved back by `off`
+                PtrsFilmPixel *band = nullptr;
+                if (ps == root) band = (PtrsFilmPixel *)root->film_tmp.p + off;
+                else { int rc2 = ps->film_tmp.ensure(bytes); if (rc2 != PTRS_OK) return rc2; band = (PtrsFilmPixel *)ps->film_tmp.p; }
+                if (film_is_zero) HIPCHK(hipMemset(band, 0, bytes)); else HIPCHK(hipMemcpy(band, film_inout + off, bytes, hipMemcpyHostToDevice));
+                PtrsRenderParams p = *params;
+                p.row_begin = bounds[i]; p.row_end = bounds[i + 1]; p.device = ps->device;
+                int rc2 = do_render(ps, camera, &p, (v4 *)(band - off), nullptr, nullptr, stats_per_scene ? &stats_per_scene[i] : nullptr, nullptr, nullptr, nullptr, std::max(1, share[i]));
+                if (rc2 != PTRS_OK || ps == root) return rc2;
+                PtrsFilmPixel *dst = (PtrsFilmPixel *)root->film_tmp.p + off;
+                const bool direct = scene_options(ps).peer_copy != 0; // (0: the test hook that forces the host-staged path, also between replicas on one device)
+                if (direct && ps->device == root->device) { HIPCHK(hipMemcpy(dst, band, bytes, hipMemcpyDeviceToDevice)); return PTRS_OK; }
+                bool pushed = false;
+                if (direct) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, ps->device, root->device) == hipSuccess && can) {
+                        const hipError_t pe = hipDeviceEnablePeerAccess(root->device, 0);
+                        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                        else (void)hipGetLastError();
+                    }
+                    if (!ps->lane_stream[0] && hipStreamCreateWithFlags(&ps->lane_stream[0], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); }
+                    if (ps->lane_stream[0] && hipMemcpyPeerAsync(dst, root->device, band, ps->device, bytes, ps->lane_stream[0]) == hipSuccess && hipStreamSynchronize(ps->lane_stream[0]) == hipSuccess) pushed = true;
+                    else (void)hipGetLastError();
+                }
+                if (!pushed) { HIPCHK(hipMemcpy(film_inout + off, band, bytes, hipMemcpyDeviceToHost)); staged[i] = 1; } // no peer path: through the host film
+                return PTRS_OK;
+            });
+            if (rcs[i] != PTRS_OK) errs[i] = g_err; // thread-local message of the worker
+        };
+        std::vector<std::thread> th;
+        try {
+            for (uint32_t i = 1; i < n; ++i) th.emplace_back(work, i);
+        } catch (...) {
+            for (auto &t : th) if (t.joinable()) t.join();
+            g_err = "cannot start a host thread per device";
+            return PTRS_ERR_DEVICE;
+        }
+        work(0); // device 0's band on the calling thread
+        for (auto &t : th) t.join();
+        for (uint32_t i = 0; i < n; ++i) if (rcs[i] != PTRS_OK) { g_err = "device " + std::to_string(scenes[i]->device) + ": " + errs[i]; return rcs[i]; }
+        HIPCHK(hipSetDevice(root->device));
+        for (uint32_t i = 1; i < n; ++i) if (staged[i]) {
             const size_t off = (size_t)bounds[i] * W, bytes = (size_t)(bounds[i + 1] - bounds[i]) * W * sizeof(PtrsFilmPixel);
-            if (!bytes || scenes[i] == root) continue;
-            PtrsFilmPixel *dst = (PtrsFilmPixel *)root->film_tmp.p + off; const PtrsFilmPixel *src = (const PtrsFilmPixel *)scenes[i]->film_tmp.p + off;
-            hipError_t e = scenes[i]->device == root->device ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, root->device, src, scenes[i]->device, bytes);
-            if (e != hipSuccess) { // no peer path: through the host film
-                (void)hipGetLastError();
-                HIPCHK(hipSetDevice(scenes[i]->device));
-                HIPCHK(hipMemcpy(film_inout + off, src, bytes, hipMemcpyDeviceToHost));
-                HIPCHK(hipSetDevice(root->device));
-                HIPCHK(hipMemcpy(dst, film_inout + off, bytes, hipMemcpyHostToDevice));
-            }
+            HIPCHK(hipMemcpy((PtrsFilmPixel *)root->film_tmp.p + off, film_inout + off, bytes, hipMemcpyHostToDevice));
         }
         HIPCHK(hipMemcpy(film_inout, root->film_tmp.p, npx * sizeof(PtrsFilmPixel), hipMemcpyDeviceToHost));
         return PTRS_OK;
@@ -1578,6 +1661,94 @@ static int trace_rays_impl(PtrsScene *scene, uint32_t n, const float *rays, int3
     bo.release(); bd.release(); bh.release(); bc.release(); bs.release(); bt.release();
     if (e != hipSuccess) { g_err = std::string("ptrs_trace_rays: ") + hipGetErrorString(e); return PTRS_ERR_DEVICE; }
     return PTRS_OK;
+}
+
+int ptrs_render_dump_rays(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, uint32_t round, uint32_t max_rays, float *rays_out, uint32_t *n_out) {
+    return guarded([&]() -> int {
+        if (!scene || !camera || !params || !rays_out || !n_out || max_rays == 0) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+        HIPCHK(hipSetDevice(scene->device));
+        DevBuf out;
+        int rc = out.ensure((size_t)max_rays * 7 * sizeof(float));
+        if (rc != PTRS_OK) return rc;
+        const size_t npx = (size_t)params->width * (size_t)params->height;
+        if ((rc = scene->film_tmp.ensure(npx * sizeof(PtrsFilmPixel))) != PTRS_OK) { out.release(); return rc; }
+        const RayDump d{round, max_rays, (float *)out.p, n_out};
+        *n_out = 0;
+        rc = do_render(scene, camera, params, (v4 *)scene->film_tmp.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, &d);
+        if (rc == PTRS_OK && *n_out && hipMemcpy(rays_out, out.p, (size_t)*n_out * 7 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { g_err = "copying the rays out failed"; rc = PTRS_ERR_DEVICE; }
+        out.release();
+        return rc;
+    });
+}
+
+// Traversal alone, the way a frame runs it: the rays are uploaded once, laid out as one pass's path state with an extension queue in
+// segments (64-ray blocks dealt round-robin, like k_generate's), and the lane-refill extension kernel of this scene (phase voting,
+// LDS-cached top / LDS form, persistent waves with tickets; no epilogue) is launched `repeats` times with an event pair each.
+int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t repeats, PtrsHit *hits_out, PtrsStats *stats) {
+    return guarded([&]() -> int {
+        if (!scene || !rays || n == 0 || repeats == 0 || !stats) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+        if (scene->H.max_depth > 64) { g_err = "BVH deeper than 64"; return PTRS_ERR_UNSUPPORTED; }
+        HIPCHK(hipSetDevice(scene->device));
+        std::memset(stats, 0, sizeof(*stats));
+        HipBackend be;
+        be.ps = scene; be.stream = nullptr; be.opt = scene_options(scene); be.sc = scene->sc;
+        be.feat_trace = scene_trace_features(scene->H);
+        be.vote = be.opt.vote >= 0 ? be.opt.vote != 0 : true;
+        be.refill = (uint32_t)(be.opt.refill > 0 ? be.opt.refill : (be.opt.refill == 0 ? 64 : ((be.vote && be.feat_trace == FEAT_SIMPLE) ? 32 : 16)));
+        be.geom4 = be.sc.n_nodes4 ? 0xffffffffu : LN_V4 * be.sc.n_nodes2 + 9u * be.sc.n_prims;
+        const uint32_t chunks = (n + 63u) / 64u, gmax = (uint32_t)scene->n_cu * 8u * (uint32_t)be.opt.grid_mult;
+        const uint32_t G = chunks < gmax ? chunks : gmax, seg_cap = ((chunks + G - 1) / G) * 64u;
+        be.G = G; be.seg_cap = seg_cap;
+        std::vector<v4> ro(n), rd(n);
+        for (uint32_t i = 0; i < n; ++i) { ro[i].x = rays[7 * i]; ro[i].y = rays[7 * i + 1]; ro[i].z = rays[7 * i + 2]; ro[i].w = rays[7 * i + 6]; rd[i].x = rays[7 * i + 3]; rd[i].y = rays[7 * i + 4]; rd[i].z = rays[7 * i + 5]; rd[i].w = 0.0f; }
+        std::vector<uint32_t> q((size_t)G * seg_cap, 0u), cnt((size_t)Q_STRIDE * G, 0u);
+        for (uint32_t c = 0; c < chunks; ++c) {
+            const uint32_t s = c % G, m = c * 64u + 64u <= n ? 64u : n - c * 64u;
+            for (uint32_t k = 0; k < m; ++k) q[(size_t)s * seg_cap + (c / G) * 64u + k] = c * 64u + k;
+            cnt[(size_t)Q_EXT * G + s] += m;
+        }
+        DevBuf bo, bd, bh, bq, bc, bt, bs;
+        auto cleanup = [&]() { bo.release(); bd.release(); bh.release(); bq.release(); bc.release(); bt.release(); bs.release(); };
+        int rc;
+        const size_t tk_words = (size_t)(repeats + 1) * TK_LAUNCH_WORDS + 4;
+        if ((rc = upload(bo, ro)) || (rc = upload(bd, rd)) || (rc = bh.ensure((size_t)n * 16)) || (rc = upload(bq, q)) || (rc = upload(bc, cnt)) || (rc = bt.ensure(tk_words * 4)) || (rc = bs.ensure(CNT_NUM * 8))) { cleanup(); return rc; }
+        hipError_t e = hipMemset(bt.p, 0, tk_words * 4);
+        if (e == hipSuccess) e = hipMemset(bs.p, 0, CNT_NUM * 8);
+        DPaths P; std::memset(&P, 0, sizeof(P)); P.ray_o = (v4 *)bo.p; P.ray_d = (v4 *)bd.p; P.hit = (u4 *)bh.p;
+        DQueues Q; std::memset(&Q, 0, sizeof(Q)); Q.ext[0] = (uint32_t *)bq.p; Q.counts = (uint32_t *)bc.p; Q.stats = (unsigned long long *)bs.p; Q.tickets = (uint32_t *)bt.p; Q.alive = (uint32_t *)bt.p + (size_t)(repeats + 1) * TK_LAUNCH_WORDS;
+        DParams R; std::memset(&R, 0, sizeof(R)); R.n_paths = n;
+        StackSpill sp = scene->spill;
+        const HipBackend::TravFn fn = be.feat_trace == FEAT_FULL ? be.pick_extend<FEAT_FULL>(be.vote, sp.p != nullptr) : (be.feat_trace == FEAT_IMG_ENV ? be.pick_extend<FEAT_IMG_ENV>(be.vote, sp.p != nullptr) : be.pick_extend<FEAT_SIMPLE>(be.vote, sp.p != nullptr));
+        const uint32_t grid = be.persistent_grid(fn, HipBackend::T_EXTEND);
+        std::vector<hipEvent_t> ev(2 * (size_t)repeats);
+        for (auto &x : ev) if (e == hipSuccess) e = hipEventCreate(&x);
+        for (uint32_t k = 0; k <= repeats && e == hipSuccess; ++k) { // launch 0 counts nodes and triangles (untimed), 1 .. repeats are timed
+            R.counters_on = k == 0 ? 1u : 0u;
+            if (k) (void)hipEventRecord(ev[2 * (k - 1)], nullptr);
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(BLOCK), 0, nullptr, R, be.sc, sp, P, Q, 0u, seg_cap, be.refill, 0u, G, (uint32_t *)bt.p + (size_t)k * TK_LAUNCH_WORDS);
+            if (k) (void)hipEventRecord(ev[2 * (k - 1) + 1], nullptr);
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipGetLastError();
+        double ms = 0.0;
+        for (uint32_t k = 0; k < repeats && e == hipSuccess; ++k) { float t = 0.0f; e = hipEventElapsedTime(&t, ev[2 * k], ev[2 * k + 1]); ms += t; }
+        for (auto &x : ev) if (x) (void)hipEventDestroy(x);
+        if (e == hipSuccess) {
+            unsigned long long hs[CNT_NUM];
+            e = hipMemcpy(hs, bs.p, sizeof(hs), hipMemcpyDeviceToHost);
+            stats->nodes_visited = hs[CNT_NODES]; stats->tris_tested = hs[CNT_TRIS];
+        }
+        if (e == hipSuccess && hits_out) {
+            std::vector<u4> hh(n);
+            e = hipMemcpy(hh.data(), bh.p, (size_t)n * 16, hipMemcpyDeviceToHost);
+            for (uint32_t i = 0; i < n; ++i) { hits_out[i].prim = hit_prim(hh[i].x); hits_out[i].b0 = u2f(hh[i].y); hits_out[i].b1 = u2f(hh[i].z); hits_out[i].b2 = u2f(hh[i].w); hits_out[i].t = 0.0f; }
+        }
+        stats->ms_trace = ms; stats->ms_extend = ms; stats->trace_launches = repeats; stats->extend_launches = repeats; stats->kernel_launches = repeats + 1; stats->rays_extension = (uint64_t)n * repeats;
+        stats->queue_segments = G; stats->grid_wgs[0] = grid; stats->resident_wgs_per_cu[0] = be.last_per_cu[HipBackend::T_EXTEND];
+        cleanup();
+        if (e != hipSuccess) { g_err = std::string("ptrs_trace_bench: ") + hipGetErrorString(e); return PTRS_ERR_DEVICE; }
+        return PTRS_OK;
+    });
 }
 
 int ptrs_sobol_samples(const PtrsRenderParams *params, uint32_t n, const int32_t *px, const int32_t *py, const uint64_t *sample_nums, const uint32_t *dims, float *out, uint64_t *index_out) {

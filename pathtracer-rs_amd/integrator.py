@@ -36,7 +36,7 @@ def load_library():
                         "There is no CPU fallback for the render path." % so)
     L = C.CDLL(so)
     L.ptrs_last_error.restype = C.c_char_p
-    if L.ptrs_abi_version() != 2:
+    if L.ptrs_abi_version() != 3:
         raise PtrsError("ABI version mismatch")
     structs = [abi.PtrsTexture, abi.PtrsMaterial, abi.PtrsMesh, abi.PtrsLight, abi.PtrsBvhNode, abi.PtrsSceneDesc, abi.PtrsCamera,
                abi.PtrsRenderParams, abi.PtrsStats, abi.PtrsHit]
@@ -44,6 +44,7 @@ def load_library():
         if L.ptrs_abi_sizeof(i) != C.sizeof(s):
             raise PtrsError("ABI struct %s: library %d bytes, binding %d bytes" % (s.__name__, L.ptrs_abi_sizeof(i), C.sizeof(s)))
     L.ptrs_set_option.argtypes = [C.c_char_p, C.c_int64]
+    L.ptrs_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.ptrs_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
     _LIB = L
     # A/B convenience of this Python host only (the library itself reads no environment): PTRS_OPT_<NAME>=<int>
@@ -133,6 +134,10 @@ class _DeviceScene:
         n, d, t = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(load_library().ptrs_scene_info(self.handle, C.byref(n), C.byref(d), C.byref(t)))
         return dict(bvh_nodes=n.value, bvh_max_depth=d.value, n_tris=t.value)
+
+    def set_option(self, name, value):
+        """ptrs_scene_set_option: this scene's renders take `value` for the knob instead of the process-wide setting."""
+        _check(load_library().ptrs_scene_set_option(self.handle, name.encode(), C.c_int64(int(value))))
 
     def close(self):
         if self.handle:
@@ -224,7 +229,11 @@ class PathIntegrator:
         self.last_stats = stats
         return stats
 
-    def render_multi(self, camera, scene, devices, bounds=None, row_cost=None):
+    def set_scene_option(self, scene, name, value):
+        """A tuning knob for this scene on this integrator's device only (ptrs_scene_set_option)."""
+        _device_scene(scene, self.device).set_option(name, value)
+
+    def render_multi(self, camera, scene, devices, bounds=None, row_cost=None, film_is_zero=False, scene_options=None):
         """ptrs_render_multi: the frame's rows split over `devices` (one PtrsScene per entry, one host thread each, bands
         gathered on the first device); bounds = n+1 row numbers, or planned by ptrs_plan_bands (weighted by row_cost when
         given).  Accumulates into camera.film.pixels; returns (bounds, [PtrsStats per device])."""
@@ -232,7 +241,10 @@ class PathIntegrator:
         n = len(devices)
         scenes = [_DeviceScene(scene, d) for d in devices]  # fresh replicas, also when several share a device
         try:
-            p = self.params(camera)
+            for k, v in (scene_options or {}).items():
+                for sc_ in scenes:
+                    sc_.set_option(k, v)
+            p = self.params(camera, flags=abi.FLAG_FILM_ZERO if film_is_zero else 0)
             cam = camera.to_abi()
             b = (C.c_int32 * (n + 1))()
             if bounds is None:
@@ -267,6 +279,28 @@ def trace_rays(scene, rays, any_hit=False, device=0, bvh=None):
     stats = abi.PtrsStats()
     _check(load_library().ptrs_trace_rays(ds.handle, rays.shape[0], C.c_void_p(rays.ctypes.data), int(any_hit), C.c_void_p(hits.ctypes.data), C.byref(stats)))
     return hits, stats
+
+
+def dump_rays(integrator, camera, scene, round_no, max_rays):
+    """ptrs_render_dump_rays: the extension rays of round `round_no` of the first pass of `integrator`'s render (n x 7: o, d, t_max)."""
+    ds = _device_scene(scene, integrator.device)
+    p = integrator.params(camera)
+    cam = camera.to_abi()
+    out = np.zeros((int(max_rays), 7), dtype=np.float32)
+    n = C.c_uint32(0)
+    _check(load_library().ptrs_render_dump_rays(ds.handle, C.byref(cam), C.byref(p), int(round_no), int(max_rays), C.c_void_p(out.ctypes.data), C.byref(n)))
+    return out[: n.value].copy()
+
+
+def trace_bench(scene, rays, repeats=5, device=0, want_hits=False):
+    """ptrs_trace_bench: closest-hit traversal of `rays` with the frame's extension kernel, `repeats` timed launches.  Returns
+    (stats, hits or None); stats.ms_trace is the sum of the timed launches, nodes_visited / tris_tested belong to one launch."""
+    ds = _device_scene(scene, device)
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
+    hits = np.zeros(rays.shape[0], dtype=abi.HIT_DTYPE) if want_hits else None
+    stats = abi.PtrsStats()
+    _check(load_library().ptrs_trace_bench(ds.handle, rays.shape[0], C.c_void_p(rays.ctypes.data), int(repeats), C.c_void_p(hits.ctypes.data) if want_hits else None, C.byref(stats)))
+    return stats, hits
 
 
 def sobol_samples(params, px, py, sample_nums, dims):

@@ -52,15 +52,31 @@ def probe_row_cost(pkg, camera, scene, max_depth, device=0, strips=64, spp=1):
     return cost
 
 
-def gather_film_rows(film, height, rank, world, group=None, dst=0, bounds=None):
+def gather_film_rows(film, height, rank, world, group=None, dst=0, bounds=None, mode="p2p", force=False):
     """film: (H, W, 4) tensor whose rows of this rank's band are valid (band_for_rank, or bounds[rank]:bounds[rank + 1] when
-    a plan is given).  After the call rank `dst` holds the complete film.  One collective (gather) of equal-size
-    slabs; unequal bands are padded to the largest band."""
-    if world == 1:
+    a plan is given).  After the call rank `dst` holds the complete film.
+    mode "p2p" (default): every other rank sends exactly its band, `dst` receives each band straight into its rows of the
+    film (one batch_isend_irecv: no padding, no staging copy -- bands of a cost-weighted plan differ in height).
+    mode "gather": one dist.gather of equal-size slabs, bands padded to the largest one (the round-2 form; also what
+    `bench.py`'s world-size-1 collective smoke runs with force=True, where there is no peer to send to)."""
+    if world == 1 and not force:
         return film
     band = (lambda r: (int(bounds[r]), int(bounds[r + 1]))) if bounds is not None else (lambda r: band_for_rank(height, r, world))
-    max_rows = max(band(r)[1] - band(r)[0] for r in range(world))
     b, e = band(rank)
+    if mode == "p2p" and world > 1:
+        ops = []
+        if rank == dst:
+            for r in range(world):
+                rb, re = band(r)
+                if r != dst and re > rb:
+                    ops.append(dist.P2POp(dist.irecv, film[rb:re], r, group))  # a contiguous slab of rows: received in place
+        elif e > b:
+            ops.append(dist.P2POp(dist.isend, film[b:e].contiguous(), dst, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return film
+    max_rows = max(band(r)[1] - band(r)[0] for r in range(world))
     if e - b == max_rows:
         send = film[b:e]
     else:

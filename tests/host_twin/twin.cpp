@@ -131,6 +131,7 @@ struct HostBackend {
         for (int32_t y = y0; y < y1; ++y) for (int32_t x = 0; x < R.W; ++x) film_item(R, S, P, table, film_px, x, y);
     }
     void publish_rows(v4 *, int32_t, int32_t) {}
+    void dump_rays(uint32_t, const RayDump &) {}
     void export_samples(float *out) {
         for (uint32_t pid = 0; pid < R.n_paths; ++pid) {
             PathCoord c = path_coord(R, S, pid);

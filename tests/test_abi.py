@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(ptrs):
     assert len(names) >= 12
     for n in names:
         assert hasattr(L, n), n
-    assert L.ptrs_abi_version() == 2
+    assert L.ptrs_abi_version() == 3
 
 
 def test_struct_sizes_match_binding(ptrs):

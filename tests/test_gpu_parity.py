@@ -436,6 +436,60 @@ def test_multi_device_render_is_bit_identical(ptrs):
         assert sum(st.samples for st in stats) == traced * 100 * 16  # each band traces its rows + 4 sample rows of apron / halo
     if cost is not None:
         assert bounds != [0, 20, 40, 60, 80]  # the weighted plan differs from equal bands
+    # a cleared film the caller vouches for (PTRS_FLAG_FILM_ZERO: bands are cleared on the devices, not uploaded), and an
+    # accumulating second render on top of the first (no flag: the host film's bands are uploaded)
+    cam.film.clear()
+    integ.render_multi(cam, scene, [0, 0, 0], film_is_zero=True)
+    assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    integ.render_multi(cam, scene, [0, 0])
+    cam2, _ = ptrs.import_scene(CORNELL, (96, 80))
+    integ.render(cam2, scene); integ.render(cam2, scene)
+    assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), cam2.film.pixels["rgb"].view(np.uint32))
+    assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), cam2.film.pixels["weight"].view(np.uint32))
+
+
+def test_multi_device_render_argument_checks_and_scene_options(ptrs):
+    """ptrs_render_multi refuses the same scene handle twice (two host threads on one workspace would race); per-scene options
+    (ptrs_scene_set_option) override the process-wide ones for that scene only and change no bit."""
+    import ctypes as C
+    from importlib import import_module
+    integ_mod = import_module("pathtracer-rs_amd.integrator")
+    cam, scene = ptrs.import_scene(CORNELL, (64, 48))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(4, cam.film.get_sample_bounds()), 5)
+    integ.render(cam, scene)
+    ref = cam.film.pixels.copy()
+    L = ptrs.load_library()
+    ds = integ_mod._DeviceScene(scene, 0)
+    try:
+        handles = (C.c_void_p * 2)(ds.handle, ds.handle)
+        p, c = integ.params(cam), cam.to_abi()
+        film = np.zeros_like(ref)
+        rc = L.ptrs_render_multi(handles, 2, C.byref(c), C.byref(p), None, C.c_void_p(film.ctypes.data), None)
+        assert rc != 0 and b"twice" in L.ptrs_last_error()
+        with pytest.raises(ptrs.PtrsError):
+            ds.set_option("lanes", 9)
+        with pytest.raises(ptrs.PtrsError):
+            ds.set_option("no_such_knob", 1)
+    finally:
+        ds.close()
+    for opts in ({"lanes": 1, "grid_mult": 2}, {"vote": 0, "refill": 48, "grid_pct": 50}):
+        cam.film.clear()
+        integ.render_multi(cam, scene, [0, 0], scene_options=opts)
+        assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    assert ptrs.get_option("lanes") == 3  # the process-wide value is untouched
+
+
+def test_multi_device_host_staged_gather(ptrs):
+    """The path ptrs_render_multi takes when two devices cannot reach each other -- bands staged through the host film -- forced
+    with the scene option peer_copy = 0, which also applies between replicas on one device."""
+    cam, scene = ptrs.import_scene(CORNELL, (64, 48))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(4, cam.film.get_sample_bounds()), 5)
+    integ.render(cam, scene)
+    ref = cam.film.pixels.copy()
+    cam.film.clear()
+    integ.render_multi(cam, scene, [0, 0, 0], scene_options={"peer_copy": 0})
+    assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), ref["weight"].view(np.uint32))
 
 
 def test_sobol_dimension_overrun_is_an_error(ptrs):
@@ -473,3 +527,32 @@ def test_cfg2_band_at_full_settings(ptrs, orc):
     assert (st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.rays_extension, ost.rays_shadow, ost.rays_mis)
     a, b = cam.film.pixels[rb:re], film_ref[rb:re]
     assert np.allclose(a["weight"], b["weight"], rtol=1e-4) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-4
+
+
+def test_trace_bench_and_ray_dump(ptrs, orc, scenes):
+    """ptrs_render_dump_rays + ptrs_trace_bench (the traversal bench of bench.py --workload trace-*): the dumped round-0 rays are the
+    camera rays of the pass, later rounds are fewer; tracing them with the frame's extension kernel gives ptrs_trace_rays' hits (which
+    the oracle pins), on a quad-form scene (with the treelet node order too) and on the LDS form."""
+    for order in (0, 1):
+        with ptrs.options(node_order=order, lanes=1):  # (one pipeline lane: the first pass then holds all samples of the frame)
+            cam, scene = scenes.triangle_soup(20000, resolution=(64, 64))
+            integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(4, cam.film.get_sample_bounds()), 8)
+            r0 = ptrs.dump_rays(integ, cam, scene, 0, 1 << 20)
+            r2 = ptrs.dump_rays(integ, cam, scene, 2, 1 << 20)
+            assert len(r0) == 68 * 68 * 4 and 0 < len(r2) < len(r0)
+            assert np.isfinite(r0[:, :6]).all() and np.allclose(np.linalg.norm(r0[:, 3:6], axis=1), 1.0, atol=1e-5)
+            for rays in (r0, r2):
+                st, hits = ptrs.trace_bench(scene, rays, repeats=2, want_hits=True)
+                ref, _ = ptrs.trace_rays(scene, rays)
+                assert st.trace_launches == 2 and st.ms_trace > 0 and st.nodes_visited > 0
+                assert np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["b0"].view(np.uint32), ref["b0"].view(np.uint32))
+                ho, _ = orc.OracleScene(scene).trace_rays(rays)
+                assert np.array_equal(hits["prim"], ho["prim"])
+            if order == 1:  # the order is not a different tree: a whole render still matches the oracle
+                _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 8)
+    cam, scene = ptrs.import_scene(CORNELL, (48, 48))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(4, cam.film.get_sample_bounds()), 6)
+    rays = ptrs.dump_rays(integ, cam, scene, 1, 1 << 20)
+    st, hits = ptrs.trace_bench(scene, rays, repeats=1, want_hits=True)
+    ref, _ = ptrs.trace_rays(scene, rays)
+    assert len(rays) > 1000 and np.array_equal(hits["prim"], ref["prim"]) and np.array_equal(hits["b2"].view(np.uint32), ref["b2"].view(np.uint32))

@@ -7,7 +7,7 @@ OUT=gpurun_out/ab_$TAG.txt
 for E in "$@"; do
   for W in ${WORKLOADS:-cornell colonnade classroom}; do
     echo "## $E $W" >> $OUT
-    env $E python bench.py --workload $W --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline 2>> gpurun_out/ab_$TAG.err | python -c "
+    env $E python bench.py --workload $W --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-collective-smoke 2>> gpurun_out/ab_$TAG.err | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
