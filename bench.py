@@ -486,7 +486,7 @@ def main():
                             "bytes_per_launch": xst.rays * b_ray / max(xst.extend_launches + xst.connect_launches, 1)},
             "classes": classes, "valu_ceiling": ceiling,
             "counters_from": pmc_meta, "counters_usable": bool(d.get("valu_pipe_frac") is not None),
-            "timing": "HIP events around every launch of ONE untimed frame on a single pipeline lane (ms_per_frame_single_lane); the timed steps run the default path on %d lanes without events" % lanes,
+            "timing": "HIP events around every launch of ONE untimed frame on a single pipeline lane (ms_per_frame_single_lane); the timed steps run the default path on %d lanes without events" % int(st.lanes),
             "single_lane_frame_ms": {"extend": xst.ms_extend, "connect": xst.ms_connect, "shade": xst.ms_shade_kernels, "aux (generate, epilogue, resolve)": xst.ms_aux, "film": xst.ms_film},
             "b_state_bytes_per_path_round": 216, "hbm_copy_measured_gbs": hbm_copy_gbs(torch, dev),
         }
@@ -515,7 +515,7 @@ def main():
                        "band_probe_ms": probe_ms, "value_incl_band_probe": rays / (dt + args.steps * probe_ms * 1e-3) / 1e6,  # a host that plans its bands per frame pays the probe per frame
                        "collective": ("none" if world == 1 else ("rccl gather of film row bands" if backend == "nccl" else backend + " gather (host-staged fallback, NOT an RCCL number)")),
                        "halo_overhead": rows_traced / float(H + 4) - 1.0, "rays_traced_incl_halo_per_step": rays_traced / args.steps,
-                       "pipeline_lanes": lanes, "timed_path": "library default (no PTRS_FLAG_TIMING)",
+                       "pipeline_lanes": int(st.lanes), "launch_share_of_resident_capacity_pct": int(st.grid_pct), "timed_path": "library default (no PTRS_FLAG_TIMING)",
                        "launch": {"queue_segments_per_pass": st.queue_segments, "passes_per_frame": st.passes, "kernel_launches_per_frame": st.kernel_launches,
                                   "workgroups_last_launch": dict(zip(("extend", "connect", "shade", "aux"), [int(x) for x in st.grid_wgs])),
                                   "resident_workgroups_per_cu": dict(zip(("extend", "connect", "shade", "aux"), [int(x) for x in st.resident_wgs_per_cu])),

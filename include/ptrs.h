@@ -217,6 +217,8 @@ typedef struct PtrsStats {
     uint64_t queue_segments;
     uint64_t grid_wgs[4];
     uint64_t resident_wgs_per_cu[4];
+    uint64_t lanes;          /* pipeline lanes the call ran on (option "lanes", or chosen by the size of the job) */
+    uint64_t grid_pct;       /* share of a kernel's resident capacity its launches took (option "grid_pct", or chosen with the lanes) */
 } PtrsStats;
 
 enum {

@@ -191,8 +191,9 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
 
 // One quad-node visit: tests the node's slots, stacks the postponed ones and returns the next reference in `cur`
 // (an inner node, a leaf, or REF_NONE when the stack has run dry).
+PT_HD uint32_t neg_bits3(const bool neg[3]) { const uint32_t b = (neg[0] ? 1u : 0u) | (neg[1] ? 2u : 0u) | (neg[2] ? 4u : 0u); return b | (b << 8) | (b << 16); } // the ray's sign bits, once per byte (DNode4::pad[0])
 template <bool ANY, class Stack, class Geom>
-PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes) {
+PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes, uint32_t negbits3) {
     v4 q[8];
     G.node8(cur, q);
     uint32_t r0 = f2u(q[6].x), r1 = f2u(q[6].y), r2 = f2u(q[6].z), r3 = f2u(q[6].w);
@@ -204,8 +205,11 @@ PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg
     bool h2 = slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2); h2 = h2 & (t2 < t_max);
     bool h3 = slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3); h3 = h3 & (t3 < t_max);
     n_nodes += (axes >> 12) & 7u;
-    const uint32_t ax = axes & 3u, aa = (axes >> 2) & 3u, ab = (axes >> 4) & 3u;
-    const bool sw = ax < 3u && neg[ax], swa = aa < 3u && neg[aa], swb = ab < 3u && neg[ab];
+    const uint32_t sx = negbits3 & f2u(q[7].y); // (the split axes as one-hot bytes against the ray's sign bits: = ax < 3 && neg[ax] etc.)
+    const bool sw = (sx & 0xffu) != 0u, swa = (sx & 0xff00u) != 0u, swb = (sx & 0xff0000u) != 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64((axes & 0x100u) != 0u) != 0ull) // (rare: the four selects run only in waves that meet such a node)
+#endif
     if (axes & 0x100u) { t0 = t1 = t2 = t3 = -3.402823466e38f; } // chunks of one leaf: no pop-time re-test
     // A slot that is not hit loses its reference, so that the reordering below moves two values per slot, not two values and a
     // lane mask (a select between lane masks is computed on 0/1 integers in vector registers); hit <=> reference left.
@@ -228,8 +232,8 @@ PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg
 }
 
 template <bool QUAD, bool ANY, class Stack, class Geom>
-PT_HD void node_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes) {
-    if (QUAD) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes); else pair_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes);
+PT_HD void node_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes, uint32_t negbits3) {
+    if (QUAD) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes, negbits3); else pair_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes);
 }
 
 // Quad-node traversal (DNode4): one fetch covers two levels of the binary tree.  Slots are visited in the order the
@@ -248,8 +252,9 @@ PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     const RayShear shear = ray_shear_inv(d, inv);
     uint32_t cur = 0;
     bool hit = false;
+    const uint32_t nb3 = neg_bits3(neg);
     while (cur != REF_NONE) {
-        while (cur != REF_NONE && !(cur & REF_LEAF)) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes);
+        while (cur != REF_NONE && !(cur & REF_LEAF)) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes, nb3);
         if (cur == REF_NONE) break;
         if (leaf_test<ANY, ALPHA>(G, sc, cur, o, shear, t_max, out, hit, n_tris)) return true;
         cur = REF_NONE;

@@ -72,13 +72,13 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
     }
     f2 pf = mk2((float)c.px + u.x, (float)c.py + u.y);
     CamRay r = camera_ray(C, pf, R.inv_sqrt_spp);
-    P.ray_o[pid] = mkv4(r.o, PT_INF);
-    P.ray_d[pid] = mkv4(r.d, u2f(st.z)); // the path's state word (dimension counter | flags | bounces) travels with the ray direction: a vertex
+    pslot(P.ray_o, pid) = mkv4(r.o, PT_INF);
+    pslot(P.ray_d, pid) = mkv4(r.d, u2f(st.z)); // the path's state word (dimension counter | flags | bounces) travels with the ray direction: a vertex
                                          // that continues rewrites ray_d anyway, and `st` keeps only what never changes (Sobol' index, scramble)
-    P.beta[pid] = mkv4(splat3(1.0f), 1.0f);
-    P.L[pid] = mkv4(splat3(0.0f), 0.0f);
-    P.st[pid] = st;
-    { f2a q; q.x = pf.x; q.y = pf.y; P.pfilm[pid] = q; }
+    pslot(P.beta, pid) = mkv4(splat3(1.0f), 1.0f);
+    pslot(P.L, pid) = mkv4(splat3(0.0f), 0.0f);
+    pslot(P.st, pid) = st;
+    { f2a q; q.x = pf.x; q.y = pf.y; pslot(P.pfilm, pid) = q; }
 }
 
 // t_max of every shadow ray: spawn_ray_to_it's 1 - 0.0001 (interaction.rs:50-60, Q13)
@@ -94,7 +94,7 @@ PT_HD uint32_t st_pack(uint32_t dim, uint32_t flags, int32_t bounces) { return (
 // Returns the bucket (0..5) when the path goes on to shading, -1 when it ends here.
 template <int FEAT>
 PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P, uint32_t pid, const HitRec &h) {
-    const v4 rdv = P.ray_d[pid];
+    const v4 rdv = pslot(P.ray_d, pid);
     const uint32_t stz = f2u(rdv.w);
     const int32_t prim = h.prim;
     const int32_t bounces = st_bounces(stz);
@@ -105,16 +105,16 @@ PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P
                 f3 d = xyz(rdv);
                 Surface s = tri_surface(T, prim, h.b0, h.b1, h.b2, -d);
                 f3 le = surface_le<FEAT>(sc, T, s, -d);
-                v4 Lv = P.L[pid];
-                f3 L = xyz(Lv) + xyz(P.beta[pid]) * le;
-                P.L[pid] = mkv4(L, Lv.w);
+                v4 Lv = pslot(P.L, pid);
+                f3 L = xyz(Lv) + xyz(pslot(P.beta, pid)) * le;
+                pslot(P.L, pid) = mkv4(L, Lv.w);
             }
         } else if ((FEAT & FEAT_INFINITE) && sc.n_inf > 0) {
             f3 d = xyz(rdv);
-            v4 Lv = P.L[pid];
-            f3 L = xyz(Lv), beta = xyz(P.beta[pid]);
+            v4 Lv = pslot(P.L, pid);
+            f3 L = xyz(Lv), beta = xyz(pslot(P.beta, pid));
             for (uint32_t i = 0; i < sc.n_inf; ++i) L = L + beta * light_le<FEAT>(sc, sc.lights[sc.inf_lights[i]], d);
-            P.L[pid] = mkv4(L, Lv.w);
+            pslot(P.L, pid) = mkv4(L, Lv.w);
         }
     }
     if (prim < 0 || bounces >= R.max_depth) return -1;
@@ -142,7 +142,11 @@ PT_HD uint32_t hit_flags(uint32_t x) { return x == 0xffffffffu ? 0u : ((((x >> 2
 #endif
 #else
 #define PT_STAMP_PARAMS
+#if defined(PTRS_SCHED_BARRIERS) && defined(__HIP_DEVICE_COMPILE__)
+#define PT_STAMP(k, dep) __builtin_amdgcn_sched_barrier(0); // A/B build: the phases of shade_item are not interleaved by the scheduler (shorter live ranges, fewer spills?)
+#else
 #define PT_STAMP(k, dep)
+#endif
 #endif
 
 // The draws of one shading vertex, for either sampler.  `field` is the dimension field of the path's state word: the Sobol'
@@ -205,7 +209,7 @@ struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; P
 // pass holds tens of GB of path state).  The gfx950 shade kernel fetches the NEXT item's PathIn while it shades the
 // current one (k_shade), which hides the one HBM round trip of the stage.
 struct PathIn { v4 ro, rd, beta; u4 st, hit; };
-PT_HD PathIn load_path_in(const DPaths &P, uint32_t pid) { PathIn p; p.ro = P.ray_o[pid]; p.rd = P.ray_d[pid]; p.beta = P.beta[pid]; p.st = P.st[pid]; p.hit = P.hit[pid]; return p; }
+PT_HD PathIn load_path_in(const DPaths &P, uint32_t pid) { PathIn p; p.ro = pslot(P.ray_o, pid); p.rd = pslot(P.ray_d, pid); p.beta = pslot(P.beta, pid); p.st = pslot(P.st, pid); p.hit = pslot(P.hit, pid); return p; }
 
 template <int MAT, int FEAT, class CTX = ShadeCtx>
 PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid, const PathIn &in, const CTX &X PT_STAMP_PARAMS) {
@@ -246,7 +250,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     // Only the camera ray carries differentials (Q9) and only image-texture lookups read them
     // (texture.rs:185-191, 430-445), so without image textures they are dead values.
     if ((FEAT & FEAT_IMAGE) && (stv.z & ST_HAS_DIFF)) {
-        const f2a pf = P.pfilm[pid];
+        const f2a pf = pslot(P.pfilm, pid);
         CamRay cr = camera_ray(C, mk2(pf.x, pf.y), R.inv_sqrt_spp);
         surface_differentials(s, ro, cr.rx_d, ro, cr.ry_d);
     }
@@ -373,12 +377,12 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     }
     // ---- the vertex's stores ------------------------------------------------------------------------------------------
     X.before_stores();
-    if (out.shadow) { P.sh_o[pid] = w_sh_o; P.sh_d[pid] = w_sh_d; }
-    if (out.mis) { P.mis_o[pid] = w_mis_o; P.mis_d[pid] = w_mis_d; }
-    if (out.mis) { P.nee0[pid] = w_nee0; P.nee1[pid] = w_nee1; P.nee2[pid] = w_nee2; } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1 / nee2)
-    if (w_pre) { if (out.next) w_ro.w = w_cz; else reinterpret_cast<float *>(P.ray_o + pid)[3] = w_cz; }
-    if (w_skip) { P.ray_o[pid] = w_ro; P.ray_d[pid] = mkv4(rd, u2f(w_stz)); out.next = true; }
-    else if (out.next) { P.ray_o[pid] = w_ro; P.ray_d[pid] = w_rd; P.beta[pid] = w_beta; }
+    if (out.shadow) { pslot(P.sh_o, pid) = w_sh_o; pslot(P.sh_d, pid) = w_sh_d; }
+    if (out.mis) { pslot(P.mis_o, pid) = w_mis_o; pslot(P.mis_d, pid) = w_mis_d; }
+    if (out.mis) { pslot(P.nee0, pid) = w_nee0; pslot(P.nee1, pid) = w_nee1; pslot(P.nee2, pid) = w_nee2; } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1 / nee2)
+    if (w_pre) { if (out.next) w_ro.w = w_cz; else reinterpret_cast<float *>(&pslot(P.ray_o, pid))[3] = w_cz; }
+    if (w_skip) { pslot(P.ray_o, pid) = w_ro; pslot(P.ray_d, pid) = mkv4(rd, u2f(w_stz)); out.next = true; }
+    else if (out.next) { pslot(P.ray_o, pid) = w_ro; pslot(P.ray_d, pid) = w_rd; pslot(P.beta, pid) = w_beta; }
     PT_STAMP(8, 0u)
     return out;
 }
@@ -392,17 +396,17 @@ template <int FEAT>
 PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, bool occluded, const HitRec &mh) {
     const uint32_t pid = entry & NEE_Q_PID;
     if (entry & NEE_Q_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, sh_o.w, ray_o.w)
-        if (!occluded) { const f3 c = mk3(P.sh_d[pid].w, P.sh_o[pid].w, P.ray_o[pid].w); const v4 Lv = P.L[pid]; P.L[pid] = mkv4(xyz(Lv) + c, Lv.w); }
+        if (!occluded) { const f3 c = mk3(pslot(P.sh_d, pid).w, pslot(P.sh_o, pid).w, pslot(P.ray_o, pid).w); const v4 Lv = pslot(P.L, pid); pslot(P.L, pid) = mkv4(xyz(Lv) + c, Lv.w); }
         return;
     }
-    const u4 n2 = P.nee2[pid];
+    const u4 n2 = pslot(P.nee2, pid);
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
-    const v4 n0 = P.nee0[pid], n1 = P.nee1[pid];
+    const v4 n0 = pslot(P.nee0, pid), n1 = pslot(P.nee1, pid);
     f3 ld = splat3(0.0f);
     if ((fl & NEE_SHADOW) && !occluded) ld = ld + xyz(n0);
     if (fl & NEE_MIS) {
         const DLight &Lt = sc.lights[li];
-        const f3 wi = xyz(P.mis_d[pid]);
+        const f3 wi = xyz(pslot(P.mis_d, pid));
         f3 l2 = splat3(0.0f);
         if (mh.prim >= 0) {
             const TriRegs T = load_tri_regs(sc.shade + mh.prim);
@@ -414,9 +418,9 @@ PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, bool 
         if (!is_black(l2)) ld = ld + xyz(n1) * l2 * splat3(1.0f) * n0.w / n1.w;
     }
     const f3 beta = mk3(u2f(n2.x), u2f(n2.y), u2f(n2.z));
-    const v4 Lv = P.L[pid];
+    const v4 Lv = pslot(P.L, pid);
     const f3 L = xyz(Lv) + beta * ((float)sc.n_lights * ld);
-    P.L[pid] = mkv4(L, Lv.w);
+    pslot(P.L, pid) = mkv4(L, Lv.w);
 }
 
 template <int FEAT, bool QUAD, class Stack, class Geom>
@@ -426,13 +430,13 @@ PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32
     bool occluded = false;
     HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
     if (fl & NEE_SHADOW) {
-        const v4 o = P.sh_o[pid], d = P.sh_d[pid];
+        const v4 o = pslot(P.sh_o, pid), d = pslot(P.sh_d, pid);
         HitRec h;
         occluded = bvh_trace_g<QUAD, true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), PT_SHADOW_TMAX, stack, h, n_nodes, n_tris); // (sh_o.w may hold a NEE_PRE record's payload)
     }
     if (fl & NEE_MIS) {
-        const v4 o = P.mis_o[pid];
-        if (!bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(P.mis_d[pid]), PT_INF, stack, mh, n_nodes, n_tris)) mh.prim = -1;
+        const v4 o = pslot(P.mis_o, pid);
+        if (!bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(pslot(P.mis_d, pid)), PT_INF, stack, mh, n_nodes, n_tris)) mh.prim = -1;
     }
     resolve_item<FEAT>(sc, P, entry, occluded, mh);
 }
@@ -483,10 +487,10 @@ PT_HD void film_item(const DParams &R, const DSampler &S, const DPaths &P, const
                 const int32_t sy = qy - S.min_y;
                 if (sy < R.row0 || sy >= R.row1) continue;
                 const uint32_t pid = k * npix + (uint32_t)(sy - R.row0) * (uint32_t)R.NX + (uint32_t)sx;
-                const f2a pf = P.pfilm[pid];
+                const f2a pf = pslot(P.pfilm, pid);
                 float w;
                 if (!film_weight(pf.x, pf.y, x, y, table, w)) continue;
-                const v4 Lv = P.L[pid];
+                const v4 Lv = pslot(P.L, pid);
                 acc.x += Lv.x * w; acc.y += Lv.y * w; acc.z += Lv.z * w; acc.w += w;
             }
         }

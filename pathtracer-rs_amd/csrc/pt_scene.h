@@ -222,6 +222,25 @@ struct DQueues {
     unsigned long long *stats; // [CNT_NUM]
 };
 
+// Element `i` of a device array through a 32-BIT byte offset (i * sizeof(T) < 2^32: a pass holds at most 2^27 paths of <= 16 bytes, a queue
+// at most 2^27 + G * 64 entries of 4): on gfx950 the access is `global_load ... v_offset, s[base]` with one shift shared by all arrays of the
+// element size, instead of a 64-bit shift-and-add per access (v_lshl_add_u64: an instruction of the half-rate class, 8 % of the Matte shade
+// kernel's) and an address register pair each.
+template <class T> PT_HD T &pslot(T *base, uint32_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (size_t)(i * (uint32_t)sizeof(T)));
+#else
+    return base[i];
+#endif
+}
+template <class T> PT_HD const T &pslot(const T *base, uint32_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(i * (uint32_t)sizeof(T)));
+#else
+    return base[i];
+#endif
+}
+
 PT_HD uint32_t f2u(float f) { return ptf_bits(f); }
 PT_HD float u2f(uint32_t u) { return ptf_from_bits(u); }
 PT_HD v4 mkv4(f3 a, float w) { v4 r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = w; return r; }

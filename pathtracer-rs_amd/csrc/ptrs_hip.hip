@@ -36,12 +36,13 @@ thread_local std::string g_err;
 // Process-wide tuning knobs (ptrs_set_option).  The library reads no environment variables: an embedding host sets what
 // it needs once; the defaults are the measured best on MI355X.
 struct Options {
-    int lanes = 3;            // concurrent pipeline lanes (own path state, queues and stream each), 1..MAX_LANES
+    int lanes = 0;            // concurrent pipeline lanes (own path state, queues and stream each), 1..MAX_LANES; 0 = by the size of the job (HipBackend::lanes)
     int refill = -1;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend; -1 = by scene (32 with phase voting and no alpha masks, else 16)
     int refill_connect = -1;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
     int grid_mult = 8;        // queue segments (one wave each) per pass: CUs x 8 x grid_mult, i.e. 16384 on MI355X at the default (Cornell single-lane frame: 4: 252 ms, 8: 216, 16: 222)
-    int grid_pct = 100;       // share of its resident capacity a persistent launch takes: below 100 a kernel leaves wave slots to the kernels of the other pipeline lanes
+    int grid_pct = 0;         // share of its resident capacity a persistent launch takes: below 100 a kernel leaves wave slots to the kernels of the other pipeline lanes; 0 = 50 with several lanes, 100 with one
+    int whole_rounds = 0;     // 1: segments per pass rounded to a whole multiple of the traversal kernels' resident waves (HipBackend::whole_rounds); measured within noise of 0 (exactly CUs x 8 x grid_mult) on Cornell / classroom, 2.5 % slower on colonnade
     int persist = 1;          // queue kernels are launched with the workgroups that fit the machine at once (occupancy x CUs); 0: with 8 per CU, the hardware's maximum (A/B hook)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
     int node_order = 0;       // quad form, records behind the LDS-cached top: 0 = the builder's depth-first order, 1 = treelets of three levels (pt_host_scene.h)
@@ -59,8 +60,8 @@ std::mutex g_opt_mu;
 Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
-    {"lanes", &Options::lanes, 1, 4}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"grid_pct", &Options::grid_pct, 10, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1},
+    {"lanes", &Options::lanes, 0, 4}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
+    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -381,19 +382,19 @@ __device__ inline GeomTop stage_top(const DScene &sc, v4 *lds, bool top) {
 // Per-lane ray state of the refill kernels: plain scalars on purpose (a struct with the sign array in it made hipcc
 // produce a 20 % slower loop).
 #define RF_DECL f3 r_o = mk3(0, 0, 0), r_inv = mk3(1, 1, 1); bool r_neg[3] = {false, false, false}; RayShear r_shear; r_shear.kz = 2; r_shear.sx = r_shear.sy = 0.0f; r_shear.sz = 1.0f; \
-                float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE;
+                float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE, r_nb3 = 0;
 #define RF_START(O, D, TMAX) { r_o = (O); const f3 d_ = (D); r_tmax = (TMAX); r_inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); \
-                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_shear = ray_shear_inv(d_, r_inv); \
+                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_nb3 = neg_bits3(r_neg); r_shear = ray_shear_inv(d_, r_inv); \
                 r_h.prim = -1; r_h.t = r_tmax; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; r_hit = false; r_cur = 0; }
 
 template <bool VOTE, bool QUAD, bool ALPHA, class Stack, class Geom>
-__device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
+__device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], uint32_t r_nb3, const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
                                Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt, StepCount &sc_n) {
     if (VOTE) {
         const bool at_node = (int32_t)r_cur >= 0, at_leaf = (int32_t)r_cur < -1; // leaf references have bit 31 set; lanes without a ray hold REF_NONE = -1
         const uint32_t n_node = rfl((uint32_t)__popcll(__ballot(at_node))), n_leaf = rfl((uint32_t)__popcll(__ballot(at_leaf))); // (scalar registers: the comparison is an s_cmp)
         if (n_node >= n_leaf) {
-            if (at_node) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
+            if (at_node) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn, r_nb3); }
         } else if (at_leaf) {
             PT_COUNT_TRI(sc_n, 1u)
             const bool done = leaf_step<ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt);
@@ -401,7 +402,7 @@ __device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur,
         }
         return;
     }
-    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn); }
+    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn, r_nb3); }
     if (r_cur != REF_NONE) {
 #ifdef PTRS_STEP_COUNTERS
         { const uint32_t k = ((r_cur >> REF_COUNT_SHIFT) & 15u) + 1u; uint32_t kmax = k; for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kmax, off); kmax = o > kmax ? o : kmax; } PT_COUNT_TRI(sc_n, kmax) } // (an upper bound, diagnostic only)
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
         for (;;) {
             if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this loop
                 u4 v; v.x = hit_pack(r_h.prim, r_h.flags); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-                P.hit[pid] = v;
+                pslot(P.hit, pid) = v;
                 has = false;
             }
             const unsigned long long idle = __ballot(!has);
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
             if (cursor < n && n_idle >= thresh) {
                 const uint32_t i = cursor + lanes_below(idle);
                 if (!has && i < n) {
-                    pid = queue[i];
-                    const v4 ov = P.ray_o[pid], dv = P.ray_d[pid];
+                    pid = pslot(queue, i);
+                    const v4 ov = pslot(P.ray_o, pid), dv = pslot(P.ray_d, pid);
                     if (GEOM > 0) LF_START(LG, xyz(ov), xyz(dv), PT_INF) else RF_START(xyz(ov), xyz(dv), PT_INF)
                     stk.clear(); has = true;
                 }
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
             if (!__any(has)) break; // every ray of the segment is retired
             do { // steps until enough lanes are through their rays: only then is there something to retire or refill
                 if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
-                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
             // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
             // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
             // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
@@ -505,15 +506,15 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
                 if (shadow_phase) {
                     if (fl & NEE_PRE) { // a shadow-only record is resolved here: l += beta * nLights * ld unless the ray was blocked (integrator.rs:66-78, 444-446)
-                        if (!r_hit) { v4 o = pre_l; o.x = pre_l.x + pre_c.x; o.y = pre_l.y + pre_c.y; o.z = pre_l.z + pre_c.z; P.L[pid] = o; }
+                        if (!r_hit) { v4 o = pre_l; o.x = pre_l.x + pre_c.x; o.y = pre_l.y + pre_c.y; o.z = pre_l.z + pre_c.z; pslot(P.L, pid) = o; }
                         has = false;
                     } else {
-                        if (r_hit) reinterpret_cast<uint32_t *>(P.nee2 + pid)[3] |= NEE_OCCLUDED << 24;
+                        if (r_hit) reinterpret_cast<uint32_t *>(&pslot(P.nee2, pid))[3] |= NEE_OCCLUDED << 24;
                         if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
                     }
                 } else {
                     u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-                    P.hit[pid] = v;
+                    pslot(P.hit, pid) = v;
                     has = false;
                 }
             }
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             if (batch && cursor < n && idle) {
                 const uint32_t i = cursor + lanes_below(idle);
                 if (!has && i < n) {
-                    const uint32_t entry = queue[i]; // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
+                    const uint32_t entry = pslot(queue, i); // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
                     pid = entry & NEE_Q_PID;
                     fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
                     if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
@@ -534,15 +535,15 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             }
             if (batch && setup) {
                 const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
-                const v4 o = po[pid], d = pd[pid];
-                if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = reinterpret_cast<const float *>(P.ray_o + pid)[3]; pre_l = P.L[pid]; } // shade_item's packing of a shadow-only record
+                const v4 o = pslot(po, pid), d = pslot(pd, pid);
+                if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = reinterpret_cast<const float *>(&pslot(P.ray_o, pid))[3]; pre_l = pslot(P.L, pid); } // shade_item's packing of a shadow-only record
                 if (GEOM > 0) LF_START(LG, xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF) else RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
                 stk.clear(); setup = false;
             }
             if (!__any(has)) break;
             do {
                 if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
-                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
             } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh)); // (see k_extend_rf)
         }
         // records with a MIS ray are resolved behind the wave's last ray (see k_extend_rf's epilogue), unless fused_resolve = 0 leaves them to k_resolve
@@ -558,12 +559,12 @@ __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQu
     const uint32_t n = rfl(*seg_count(Q, it, Q_NEE, G, s));
     if (rfl(*seg_count(Q, it, Q_MIS, G, s)) == 0) return; // every record of the segment was shadow-only: k_connect_rf has resolved them
     for (uint32_t i = __lane_id(); i < n; i += 64u) {
-        const uint32_t entry = queue[i];
+        const uint32_t entry = pslot(queue, i);
         if (entry & NEE_Q_PRE) continue; // shadow-only: resolved when its ray retired
         const uint32_t pid = entry & NEE_Q_PID;
-        const uint32_t fl = P.nee2[pid].w >> 24;
+        const uint32_t fl = pslot(P.nee2, pid).w >> 24;
         HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
-        if (fl & NEE_MIS) { const u4 v = P.hit[pid]; mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
+        if (fl & NEE_MIS) { const u4 v = pslot(P.hit, pid); mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
         resolve_item<FEAT>(sc, P, pid, (fl & NEE_OCCLUDED) != 0, mh);
     }
 }
@@ -585,8 +586,8 @@ __device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const D
         const uint32_t i = i0 + lane;
         int k = -1; uint32_t pid = 0;
         if (i < n) {
-            pid = queue[i];
-            const u4 r = P.hit[pid];
+            pid = pslot(queue, i);
+            const u4 r = pslot(P.hit, pid);
             HitRec h; h.prim = hit_prim(r.x); h.t = 0.0f; h.b0 = u2f(r.y); h.b1 = u2f(r.z); h.b2 = u2f(r.w);
             h.flags = hit_flags(r.x); // the two fields of the leaf record's flags the epilogue reads
             k = extension_epilogue<FEAT>(R, sc, P, pid, h);
@@ -595,7 +596,7 @@ __device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const D
         for (int m = 0; m < 6; ++m) { // wavefront-ballot bucketing by material kind
             if (!(kinds_mask & (1u << m))) continue;
             const uint32_t slot = wave_push(cnt[m], k == m);
-            if (k == m) Q.mat[m][(size_t)s * seg_cap + slot] = pid;
+            if (k == m) pslot(Q.mat[m] + (size_t)s * seg_cap, slot) = pid;
         }
     }
     if (lane == 0) {
@@ -622,7 +623,10 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
 #ifndef PTRS_SHADE_WAVES_MATTE
 #define PTRS_SHADE_WAVES_MATTE 3
 #endif
-template <int MAT, int FEAT> struct ShadeWaves { enum { N = ((MAT == 0 && FEAT == FEAT_SIMPLE) || (MAT == 4 && FEAT == FEAT_IMG)) ? PTRS_SHADE_WAVES_MATTE : 2 }; }; // 2: never above 256 registers (one wave per SIMD otherwise)
+#ifndef PTRS_SHADE_WAVES_DISNEY_IMG
+#define PTRS_SHADE_WAVES_DISNEY_IMG 3
+#endif
+template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT == FEAT_SIMPLE) ? PTRS_SHADE_WAVES_MATTE : ((MAT == 4 && FEAT == FEAT_IMG) ? PTRS_SHADE_WAVES_DISNEY_IMG : 2) }; }; // 2: never above 256 registers (one wave per SIMD otherwise)
 
 // The shade kernels' read-only tables in LDS.  A shading vertex issues ~150 vector-memory instructions -- path state,
 // the triangle's record, 32 Sobol' table words, the light's record, spills -- and the kernel's time is the time the
@@ -741,11 +745,11 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     auto dma = [&](uint32_t p) {
         typedef __attribute__((address_space(1))) const void gptr; typedef __attribute__((address_space(3))) void lptr;
-        if (FEAT & FEAT_IMAGE) __builtin_amdgcn_global_load_lds((gptr *)(P.ray_o + p), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0); // (the ray's origin is only read for the camera ray's differentials, which only image-texture lookups use)
-        __builtin_amdgcn_global_load_lds((gptr *)(P.ray_d + p), (lptr *)(lds_pf + (1u * 4u + wv) * 64u), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr *)(P.beta + p), (lptr *)(lds_pf + (2u * 4u + wv) * 64u), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr *)(P.st + p), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr *)(P.hit + p), (lptr *)(lds_pf + (4u * 4u + wv) * 64u), 16, 0, 0);
+        if (FEAT & FEAT_IMAGE) __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.ray_o, p), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0); // (the ray's origin is only read for the camera ray's differentials, which only image-texture lookups use)
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.ray_d, p), (lptr *)(lds_pf + (1u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.beta, p), (lptr *)(lds_pf + (2u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.st, p), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.hit, p), (lptr *)(lds_pf + (4u * 4u + wv) * 64u), 16, 0, 0);
     };
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
         const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)s * seg_cap;
@@ -757,8 +761,8 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         uint32_t *nee = Q.nee + (size_t)s * seg_cap + nee_base;
         uint32_t c_next = 0, c_nee = 0, c_shadow = 0, c_mis = 0; // the segment's output counters: wave-uniform, scalar registers
         uint32_t i = lane, pid = 0, pid1 = 0;
-        if (i < n) { pid = queue[i]; dma(pid); }
-        if (i + 64u < n) pid1 = queue[i + 64u];
+        if (i < n) { pid = pslot(queue, i); dma(pid); }
+        if (i + 64u < n) pid1 = pslot(queue, i + 64u);
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first item's state is in LDS
         while (i < n) {
             PathIn in;
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
             const uint32_t i2 = i + 64u;
             if (i2 < n) dma(pid1);
             uint32_t pid2 = 0;
-            if (i2 + 64u < n) pid2 = queue[i2 + 64u];
+            if (i2 + 64u < n) pid2 = pslot(queue, i2 + 64u);
 #ifdef PTRS_STAMPS
             const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X, stamp_acc, stamp_last);
             { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[9] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; } // early returns land here
@@ -783,9 +787,9 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
 #endif
             err_dim = err_dim || r.err_dim;
             uint32_t slot = wave_push(c_next, r.next);
-            if (r.next) next[slot] = pid;
+            if (r.next) pslot(next, slot) = pid;
             slot = wave_push(c_nee, r.nee);
-            if (r.nee) nee[slot] = r.nee_entry(pid);
+            if (r.nee) pslot(nee, slot) = r.nee_entry(pid);
             c_shadow += (uint32_t)__popcll(__ballot(r.shadow));
             c_mis += (uint32_t)__popcll(__ballot(r.mis));
             i = i2; pid = pid1; pid1 = pid2;
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P,
             float pfx = -1.0e9f, pfy = -1.0e9f, lr = 0.0f, lg = 0.0f, lb = 0.0f; // far away: no pixel is in its footprint
             if (sx >= 0 && sx < R.NX && sy >= R.row0 && sy < R.row1) {
                 const uint32_t pid = k * npix + (uint32_t)(sy - R.row0) * (uint32_t)R.NX + (uint32_t)sx;
-                const f2a pf = P.pfilm[pid]; const v4 Lv = P.L[pid];
+                const f2a pf = pslot(P.pfilm, pid); const v4 Lv = pslot(P.L, pid);
                 pfx = pf.x; pfy = pf.y; lr = Lv.x; lg = Lv.y; lb = Lv.z;
             }
             v4 a; a.x = pfx; a.y = pfy; a.z = lr; a.w = lg; s_a[e] = a; s_lb[e] = lb;
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(BLOCK) void k_dump_rays(DPaths P, DQueues Q, uint32
         base = rfl(base);
         if (i < n && base + lane < max_rays) {
             const uint32_t pid = queue[i];
-            const v4 o = P.ray_o[pid], d = P.ray_d[pid];
+            const v4 o = pslot(P.ray_o, pid), d = pslot(P.ray_d, pid);
             float *r = out + (size_t)(base + lane) * 7u;
             r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = PT_INF;
         }
@@ -896,7 +900,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_samples(DParams R, DSampler S,
     for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < R.n_paths; pid += stride) {
         const PathCoord c = path_coord(R, S, pid);
         const size_t o = R.pixel_mode ? (size_t)c.s * 3 : (((size_t)c.sy * (size_t)R.NX + (size_t)c.sx) * S.spp + c.s) * 3;
-        const v4 L = P.L[pid];
+        const v4 L = pslot(P.L, pid);
         out[o] = L.x; out[o + 1] = L.y; out[o + 2] = L.z;
     }
 }
@@ -1026,7 +1030,21 @@ struct HipBackend {
     Lane lane_[MAX_LANES]; uint32_t n_lanes = 3, cur = 0; // measured on Cornell: 1 lane 5376, 2: 6395, 3: 6578, 4: 6618 Mray/s
     hipEvent_t film_prev = nullptr;
     Options opt;
-    uint32_t lanes() { n_lanes = (uint32_t)(opt.lanes < 1 ? 1 : (opt.lanes > MAX_LANES ? MAX_LANES : opt.lanes)); return n_lanes; } // called before begin()
+    // Pipeline lanes of this render (called before begin()).  lanes = 0: by the size of the job -- a frame that fits one pass runs on one
+    // lane (its kernels are as long as they can be; measured on colonnade, 59 M paths: 1 lane 119 ms, 3 lanes 135 ms), a longer one on
+    // three, whose kernels then take half of their resident capacity each (grid_pct) so that a traversal kernel and a shade kernel of
+    // two lanes share the CUs (Cornell, 271 M paths: 1 lane 192 ms, 3 lanes 176 ms, 3 lanes at half capacity 169 ms).
+    uint32_t lanes(uint64_t job_paths = 0, const bool *kinds = nullptr) {
+        int want = opt.lanes;
+        if (want == 0) {
+            const bool none[7] = {false, false, false, false, false, false, false};
+            const uint64_t one_pass = std::min<uint64_t>(1ull << 27, auto_capacity(1, kinds ? kinds : none));
+            want = job_paths <= one_pass ? 1 : 3;
+        }
+        n_lanes = (uint32_t)(want < 1 ? 1 : (want > MAX_LANES ? MAX_LANES : want));
+        if (opt.grid_pct == 0) opt.grid_pct = n_lanes > 1 ? 50 : 100;
+        return n_lanes;
+    }
     void select(uint32_t l) {
         if (l == cur) return;
         lane_[cur] = Lane{stream, R, P, Q, G, seg_cap};
@@ -1088,26 +1106,39 @@ struct HipBackend {
     // more than the segments need (4 waves = 4 segments per workgroup).  A launch that over-estimates the residency loses nothing:
     // workgroups that start late find the ticket counter exhausted and leave.
     uint32_t last_grid[T_NUM] = {0, 0, 0, 0, 0}, last_per_cu[T_NUM] = {0, 0, 0, 0, 0}; // last launch of each class (PtrsStats)
-    template <class F> uint32_t persistent_grid(F fn, int cat) {
+    template <class F> int wgs_per_cu(F fn) {
         const void *key = reinterpret_cast<const void *>(fn);
         auto itr = ps->occupancy.find(key);
-        int per_cu;
-        if (itr == ps->occupancy.end()) {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
-            per_cu = nb > 8 ? 8 : nb;
-            ps->occupancy[key] = per_cu;
-        } else per_cu = itr->second;
-        if (!opt.persist) per_cu = 8;
-        const uint32_t need = (G + WAVES - 1) / WAVES, fit = std::max(1u, (uint32_t)ps->n_cu * (uint32_t)per_cu * (uint32_t)opt.grid_pct / 100u);
-        last_grid[cat] = need < fit ? need : fit; last_per_cu[cat] = (uint32_t)per_cu;
+        if (itr != ps->occupancy.end()) return opt.persist ? itr->second : 8;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+        ps->occupancy[key] = nb > 8 ? 8 : nb;
+        return opt.persist ? ps->occupancy[key] : 8;
+    }
+    template <class F> uint32_t resident_grid(F fn) { return std::max(1u, (uint32_t)ps->n_cu * (uint32_t)wgs_per_cu(fn) * (uint32_t)(opt.grid_pct ? opt.grid_pct : 100) / 100u); } // workgroups a launch of fn holds
+    template <class F> uint32_t persistent_grid(F fn, int cat) {
+        const uint32_t need = (G + WAVES - 1) / WAVES, fit = resident_grid(fn);
+        last_grid[cat] = need < fit ? need : fit; last_per_cu[cat] = (uint32_t)wgs_per_cu(fn);
         return last_grid[cat];
+    }
+    // Segments per pass: about CUs x 8 x grid_mult, but a WHOLE multiple of the waves the traversal kernels hold (and of the first shade
+    // kernel's, where one number serves both).  A launch of W resident waves works through G equal segments in ceil(G / W) rounds, the last
+    // one only partly filled: at G / W = 2.67 a third of the waves idle for the last third of every kernel (utilisation G / W / ceil(G / W) =
+    // 0.89; the same at 5.33), at a whole ratio none do.
+    template <int FEAT_T> uint32_t whole_rounds(uint32_t target) {
+        const uint32_t we = resident_grid(pick_extend<FEAT_T>(vote, ps->spill.p != nullptr)) * WAVES;
+        uint32_t ws = 0;
+        for (int k = 0; k < 6 && !ws; ++k) if (ps->H.kinds_present[k]) ws = resident_grid(shade_fn(k)) * WAVES;
+        auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+        uint64_t unit = we;
+        if (ws) { const uint64_t l = (uint64_t)we / gcd(we, ws) * ws; if (l <= 2ull * target) unit = l; }
+        const uint64_t k = std::max<uint64_t>(1, (target + unit / 2) / unit);
+        return (uint32_t)std::min<uint64_t>(k * unit, 4ull * target);
     }
     uint32_t *ticket(uint32_t it, int which) { return Q.tickets + ((size_t)it * Q_STRIDE + (size_t)which) * TK_LAUNCH_WORDS; }
 
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
-        grid_max = ps->n_cu * 8 * opt.grid_mult;
         // phase voting: quad-node scenes gain in both traversal kernels; on the LDS pair form a step is cheap enough that the vote's
         // own instructions eat the gain in the connect kernel (+20 %), the extension kernel keeps 4 % (A/B on MI355X)
         vote = opt.vote >= 0 ? opt.vote != 0 : true;
@@ -1119,6 +1150,8 @@ struct HipBackend {
         refill_connect = (uint32_t)(opt.refill_connect > 0 ? opt.refill_connect : (opt.refill_connect == 0 ? 64 : ((vote_connect && feat_trace == FEAT_SIMPLE) ? 32 : 16)));
         geom4 = sc.n_nodes4 ? 0xffffffffu : LN_V4 * sc.n_nodes2 + 9u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction (pt_host_scene.h)
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
+        grid_max = ps->n_cu * 8 * opt.grid_mult;
+        if (opt.persist && opt.whole_rounds) grid_max = (int)(feat_trace == FEAT_FULL ? whole_rounds<FEAT_FULL>((uint32_t)grid_max) : (feat_trace == FEAT_IMG_ENV ? whole_rounds<FEAT_IMG_ENV>((uint32_t)grid_max) : whole_rounds<FEAT_SIMPLE>((uint32_t)grid_max)));
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + ((size_t)grid_max + 1) * 64) * 4; // queues: G segments of whole 64-entry chunks
         if ((rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
         for (uint32_t l = 0; l < n_lanes && n_lanes > 1; ++l) {
@@ -1214,22 +1247,22 @@ struct HipBackend {
         return c;
     }
     typedef void (*ShadeFn)(DParams, DSampler, DCamera, DScene, DPaths, DQueues, uint32_t, uint32_t, ShadeLdsCfg, uint32_t, uint32_t *);
-    template <int FEAT> void shade_t(uint32_t it, int kind) {
-        const ShadeLdsCfg cfg = shade_cfg(it);
-        ShadeFn fn;
+    template <int FEAT> ShadeFn shade_fn_t(int kind) {
         switch (kind) {
-            case 0: fn = k_shade<0, FEAT>; break;
-            case 1: fn = k_shade<1, FEAT>; break;
-            case 2: fn = k_shade<2, FEAT>; break;
-            case 3: fn = k_shade<3, FEAT>; break;
-            case 4: fn = k_shade<4, FEAT>; break;
-            default: fn = k_shade<5, FEAT>; kind = 5; break;
+            case 0: return k_shade<0, FEAT>;
+            case 1: return k_shade<1, FEAT>;
+            case 2: return k_shade<2, FEAT>;
+            case 3: return k_shade<3, FEAT>;
+            case 4: return k_shade<4, FEAT>;
+            default: return k_shade<5, FEAT>;
         }
-        hipLaunchKernelGGL(fn, dim3(persistent_grid(fn, T_SHADE)), dim3(BLOCK), 0, stream, R, S, C, sc, P, Q, it, seg_cap, cfg, G, ticket(it, TK_SHADE0 + kind));
     }
+    ShadeFn shade_fn(int kind) { return feat == FEAT_SIMPLE ? shade_fn_t<FEAT_SIMPLE>(kind) : (feat == FEAT_IMG ? shade_fn_t<FEAT_IMG>(kind) : (feat == FEAT_IMG_ENV ? shade_fn_t<FEAT_IMG_ENV>(kind) : shade_fn_t<FEAT_FULL>(kind))); }
     void shade(uint32_t it, int kind) {
         t0(T_SHADE);
-        if (feat == FEAT_SIMPLE) shade_t<FEAT_SIMPLE>(it, kind); else if (feat == FEAT_IMG) shade_t<FEAT_IMG>(it, kind); else if (feat == FEAT_IMG_ENV) shade_t<FEAT_IMG_ENV>(it, kind); else shade_t<FEAT_FULL>(it, kind);
+        if (kind > 5) kind = 5;
+        const ShadeFn fn = shade_fn(kind);
+        hipLaunchKernelGGL(fn, dim3(persistent_grid(fn, T_SHADE)), dim3(BLOCK), 0, stream, R, S, C, sc, P, Q, it, seg_cap, shade_cfg(it), G, ticket(it, TK_SHADE0 + kind));
         t1();
     }
     void reduce_counts(uint32_t n_rows) { hipLaunchKernelGGL(k_reduce_counts, dim3(n_rows * Q_STRIDE), dim3(BLOCK), 0, stream, (const uint32_t *)Q.counts, G, (uint32_t *)ps->totals[cur].p); }
@@ -1288,7 +1321,7 @@ struct HipBackend {
             }
         }
         st.ms_trace = st.ms_extend + st.ms_connect; st.ms_shade = st.ms_shade_kernels + st.ms_aux;
-        st.queue_segments = G;
+        st.queue_segments = G; st.lanes = n_lanes; st.grid_pct = (uint64_t)(opt.grid_pct ? opt.grid_pct : 100);
         { const int cls[4] = {T_EXTEND, T_CONNECT, T_SHADE, T_AUX}; for (int k = 0; k < 4; ++k) { st.grid_wgs[k] = last_grid[cls[k]]; st.resident_wgs_per_cu[k] = last_per_cu[cls[k]]; } }
         st.extend_launches = cat_launches[T_EXTEND]; st.connect_launches = cat_launches[T_CONNECT]; st.shade_launches = cat_launches[T_SHADE]; st.aux_launches = cat_launches[T_AUX]; st.film_launches = cat_launches[T_FILM];
         size_t bytes = 0;

@@ -476,7 +476,7 @@ def test_multi_device_render_argument_checks_and_scene_options(ptrs):
         cam.film.clear()
         integ.render_multi(cam, scene, [0, 0], scene_options=opts)
         assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
-    assert ptrs.get_option("lanes") == 3  # the process-wide value is untouched
+    assert ptrs.get_option("lanes") == 0  # the process-wide value is untouched
 
 
 def test_multi_device_host_staged_gather(ptrs):
