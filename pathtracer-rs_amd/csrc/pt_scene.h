@@ -45,7 +45,10 @@ struct alignas(16) DNode4 {
     uint32_t axes, pad[3];
 };
 static_assert(sizeof(DNode4) == 128, "node4");
-enum : uint32_t { QUAD_TOP_NODES = 85 }; // 1 + 4 + 16 + 64 records of the quad tree's top, kept in LDS by the traversal kernels (10.6 KB)
+#ifndef PTRS_QUAD_TOP_NODES
+#define PTRS_QUAD_TOP_NODES 85
+#endif
+enum : uint32_t { QUAD_TOP_NODES = PTRS_QUAD_TOP_NODES }; // 1 + 4 + 16 + 64 records of the quad tree's top, kept in LDS by the traversal kernels (10.6 KB)
 enum : uint32_t { PAIR_FORM_MAX_V4 = 1536 }; // largest scene the traversal kernels stage into LDS, in 16-byte vectors of its LDS form: 7 per pair node (its planes per axis and ray sign), 9 per triangle (three permuted copies)
 enum : uint32_t { REF_LEAF = 0x80000000u, REF_NONE = 0xffffffffu, REF_FIRST_MASK = 0x07ffffffu, REF_COUNT_SHIFT = 27, REF_MAX_LEAF = 16 };
 

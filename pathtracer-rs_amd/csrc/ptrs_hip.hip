@@ -416,14 +416,18 @@ __device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const D
 template <int FEAT>
 __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t G, uint32_t s); // below, with k_resolve
 
-// Waves per SIMD the traversal kernels are compiled for.  The quad-form kernels without alpha masks sit at the edge of 96
-// registers (5 waves), and a few registers more cost a wave and 4 % of the kernel's time (colonnade k_connect_rf: 92 -> 101
-// registers, 36.7 -> 38.2 ms): the hint pins them at 5, the small LDS-resident pair form at 6 (74-80 registers).  The others
-// are left to the compiler (0 = no hint): LDS holds them at 4 waves anyway, or the full feature set needs 110-120 registers.
+// Waves per SIMD the traversal kernels are compiled for.  Quad form (tree in HBM / L2): the kernels wait for node fetches half of their
+// wave time (L2 hit rate 0.47-0.57), so a fifth wave pays even where it costs spills -- the full-feature kernels need 110-122 registers
+// and take 4-14 spilled ones at 96, almost all in the epilogue / resolve code behind the loop: classroom extend 211 -> 197 ms, connect
+// 340 -> 319 ms, frame 923 -> 863 ms.  A sixth wave (80 registers, and only 21 instead of 85 top records in LDS to make room) loses it
+// again: colonnade +3 %, classroom +1 %.  LDS form: 6 (the loop needs 61-76 registers).
+#ifndef PTRS_QUAD_WAVES
+#define PTRS_QUAD_WAVES 5
+#endif
 #ifndef PTRS_LDS_WAVES
 #define PTRS_LDS_WAVES 6
 #endif
-template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? PTRS_LDS_WAVES : ((GEOM == 0 && DEPTH == 8 && FEAT == FEAT_SIMPLE) ? 5 : 0) }; };
+template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? PTRS_LDS_WAVES : ((GEOM == 0 && DEPTH == 8) ? PTRS_QUAD_WAVES : 0) }; };
 template <int DEPTH, int GEOM> struct TravLds { enum { TOP = GEOM == 0 && DEPTH == 8, V4 = GEOM > 0 ? GEOM : (TOP ? TOP_LDS_STRIDE * QUAD_TOP_NODES : 1) }; }; // quad form with the small stack column: the tree's top lives in LDS
 
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
