@@ -199,6 +199,7 @@ struct ShadeCtx {
     PT_MEM TriRegs tri(const DScene &sc, int32_t prim, bool want_dp) const { return load_tri_regs(sc.shade + prim, want_dp); }
     PT_MEM void light(const DScene &sc, uint32_t li, DLight &out) const { out = sc.lights[li]; }
     PT_MEM const InfMarginal *inf_marginal(uint32_t) const { return nullptr; }
+    PT_MEM bool presampled(uint32_t) const { return false; } // (the gfx950 pipeline evaluates the environment light's samples of a round ahead of its shade kernels: k_env_presample)
     template <int N> PT_MEM void sobol(const DSampler &S, uint64_t index, const uint32_t (&dim)[N], uint32_t scramble, float (&out)[N]) const { sobol_batch<N>(S, index, dim, scramble, out); }
     PT_MEM void before_stores() const {}
 };
@@ -208,8 +209,8 @@ struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; P
 // What a shading vertex reads of its path: five 16-byte vectors out of HBM (nothing else of a path is cache-resident: a
 // pass holds tens of GB of path state).  The gfx950 shade kernel fetches the NEXT item's PathIn while it shades the
 // current one (k_shade), which hides the one HBM round trip of the stage.
-struct PathIn { v4 ro, rd, beta; u4 st, hit; };
-PT_HD PathIn load_path_in(const DPaths &P, uint32_t pid) { PathIn p; p.ro = pslot(P.ray_o, pid); p.rd = pslot(P.ray_d, pid); p.beta = pslot(P.beta, pid); p.st = pslot(P.st, pid); p.hit = pslot(P.hit, pid); return p; }
+struct PathIn { v4 ro, rd, beta; u4 st, hit; v4 pre0, pre1; }; // pre0 / pre1: the vertex's presampled environment-light sample (wi, pdf | Li, valid), where the context says so
+PT_HD PathIn load_path_in(const DPaths &P, uint32_t pid) { PathIn p; p.ro = pslot(P.ray_o, pid); p.rd = pslot(P.ray_d, pid); p.beta = pslot(P.beta, pid); p.st = pslot(P.st, pid); p.hit = pslot(P.hit, pid); p.pre0 = p.pre1 = mkv4(splat3(0.0f), 0.0f); return p; }
 
 template <int MAT, int FEAT, class CTX = ShadeCtx>
 PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid, const PathIn &in, const CTX &X PT_STAMP_PARAMS) {
@@ -279,7 +280,11 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         const f2 u_light = mk2(u_nee[0], u_nee[1]), u_scat = mk2(u_nee[2], u_nee[3]);
         const bool delta = light_is_delta(Lt);
         LightSample ls;
-        light_sample_li<FEAT>(sc, Lt, s.p, sp, u_light, ls, X.inf_marginal(li));
+        if ((FEAT & FEAT_INFINITE) && X.presampled(li)) { // inf_light_sample(u_light) of this vertex, evaluated by k_env_presample: the same function of the same numbers
+            ls.p1_err = splat3(0.0f); ls.p1_n = splat3(0.0f);
+            ls.wi = xyz(in.pre0); ls.pdf = in.pre0.w; ls.li = xyz(in.pre1);
+            ls.p1 = f2u(in.pre1.w) ? s.p + ls.wi * (2.0f * Lt.world_radius) : s.p;
+        } else light_sample_li<FEAT>(sc, Lt, s.p, sp, u_light, ls, X.inf_marginal(li));
         PT_STAMP(4, f2u(ls.pdf) + f2u(ls.wi.x) + f2u(ls.li.x) + f2u(ls.p1.x))
         f3 A = splat3(0.0f);
         float spdf = 0.0f;

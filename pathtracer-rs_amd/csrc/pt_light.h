@@ -94,6 +94,27 @@ PT_HD float dist1d_sample(const float *func, const float *cdf, float func_int, u
 // global pool: the gfx950 shade kernels keep it in LDS, which takes three links out of the dependent-load chain of a light sample.
 struct InfMarginal { const float *func, *cdf, *guide; };
 
+// InfiniteAreaLight::sample_li (light.rs:402-441) up to the point that depends on the shading point: direction, pdf and radiance are
+// functions of the two random numbers alone (Distribution2D::sample_continuous, sampling.rs:185-230).  On its own because the gfx950
+// pipeline evaluates it for a whole round's vertices in a kernel of its own (k_env_presample), where its chain of ~8 dependent table
+// reads runs at full occupancy instead of inside the 2-waves-per-SIMD shade kernels.  false: map_pdf == 0 (light.rs:411-413).
+PT_HD bool inf_light_sample(const DScene &sc, const DLight &L, f2 u, f3 &wi, float &pdf, f3 &li, const InfMarginal *im = nullptr) {
+    const float *D = sc.distdata;
+    float pdf_v, pdf_u; uint32_t v, dummy;
+    const float *mf = im ? im->func : D + L.fint_off, *mc = im ? im->cdf : D + L.mcdf_off, *mg = im ? im->guide : D + L.mguide_off; // same tables, same values
+    float d1 = dist1d_sample(mf, mc, L.marg_int, (uint32_t)L.nv, u.y, pdf_v, v, mg, L.guide_v);
+    float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), mf[v], (uint32_t)L.nu, u.x, pdf_u, dummy,
+                             D + L.cguide_off + (uint64_t)v * (L.guide_u + 1u), L.guide_u);
+    float map_pdf = pdf_u * pdf_v;
+    if (map_pdf == 0.0f) { li = splat3(0.0f); pdf = 0.0f; wi = splat3(0.0f); return false; }
+    float theta = d1 * PT_PI, phi = d0 * 2.0f * PT_PI;
+    float ct, st, sp, cp; pt_sincosf(theta, &st, &ct); pt_sincosf(phi, &sp, &cp);
+    wi = xform_vec(L.l2w, mk3(st * cp, st * sp, ct));
+    pdf = st == 0.0f ? 0.0f : map_pdf / (2.0f * PT_PI * PT_PI * st);
+    li = env_lookup(sc, L, mk2(d0, d1));
+    return true;
+}
+
 // Light::sample_li.  Returns false when the reference leaves the visibility tester unset
 // (InfiniteAreaLight with map_pdf == 0, light.rs:411-413) -- the reference would panic there.
 template <int FEAT>
@@ -124,21 +145,9 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const Sp
     }
     if (!(FEAT & FEAT_INFINITE)) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; } // unreachable
     // infinite area light
-    const float *D = sc.distdata;
-    float pdf_v, pdf_u; uint32_t v, dummy;
-    const float *mf = im ? im->func : D + L.fint_off, *mc = im ? im->cdf : D + L.mcdf_off, *mg = im ? im->guide : D + L.mguide_off; // same tables, same values
-    float d1 = dist1d_sample(mf, mc, L.marg_int, (uint32_t)L.nv, u.y, pdf_v, v, mg, L.guide_v);
-    float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), mf[v], (uint32_t)L.nu, u.x, pdf_u, dummy,
-                             D + L.cguide_off + (uint64_t)v * (L.guide_u + 1u), L.guide_u);
-    float map_pdf = pdf_u * pdf_v;
-    if (map_pdf == 0.0f) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; }
-    float theta = d1 * PT_PI, phi = d0 * 2.0f * PT_PI;
-    float ct, st, sp, cp; pt_sincosf(theta, &st, &ct); pt_sincosf(phi, &sp, &cp);
-    o.wi = xform_vec(L.l2w, mk3(st * cp, st * sp, ct));
-    o.pdf = st == 0.0f ? 0.0f : map_pdf / (2.0f * PT_PI * PT_PI * st);
-    o.p1 = ref_p + o.wi * (2.0f * L.world_radius);
-    o.li = env_lookup(sc, L, mk2(d0, d1));
-    return true;
+    const bool ok = inf_light_sample(sc, L, u, o.wi, o.pdf, o.li, im);
+    o.p1 = ok ? ref_p + o.wi * (2.0f * L.world_radius) : ref_p;
+    return ok;
 }
 
 template <int FEAT>

@@ -249,6 +249,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     bool null_skip_overrun = false;
     auto round = [&](uint32_t i) {
         be.extend(i);                                                     // closest hit + emission / miss / depth cut + material buckets
+        be.presample(i);                                                  // (gfx950: the environment light's samples of the round's vertices, ahead of the shade kernels)
         for (int k = 0; k < 6; ++k) if (kinds_present[k]) be.shade(i, k); // one specialised kernel per material bucket
         be.connect(i);                                                    // shadow + MIS queries, resolve into L
     };

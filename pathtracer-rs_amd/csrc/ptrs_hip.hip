@@ -52,6 +52,7 @@ struct Options {
     int fused_epilogue = 1;   // k_extend_rf / k_connect_rf run their segment's epilogue (emission, depth cut, material bucketing) / MIS resolve behind their last ray; 0: the separate k_epilogue / k_resolve
     int fused_resolve = 1;    // (with fused_epilogue) k_connect_rf resolves its MIS records itself
     int shade_lds = 1;        // shade kernels read light records, small scenes' triangle records and the round's Sobol' tables from LDS (0: everything from global memory)
+    int env_presample = 1;    // scenes lit by an environment map: the light's samples of a round's vertices are evaluated by k_env_presample ahead of the shade kernels (0: inside them)
     int peer_copy = 1;        // ptrs_render_multi: bands travel device to device (hipMemcpyPeerAsync over xGMI); 0: staged through the host film, the path taken when two devices cannot reach each other (test hook)
     int workspace_pct = 40;   // the render workspace (path state + queues of all lanes) may take this share of the device memory that is free at the call
 };
@@ -61,7 +62,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 0, 4}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1},
+    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1}, {"env_presample", &Options::env_presample, 0, 1},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -124,7 +125,7 @@ __device__ inline uint32_t seg_next(uint32_t *ticket, uint32_t G) {
 }
 // counts[(row * Q_STRIDE + q) * G + s]
 __device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uint32_t G, uint32_t s) { return Q.counts + ((size_t)row * Q_STRIDE + (size_t)q) * G + s; }
-enum { TK_EXTEND = 0, TK_CONNECT = 1, TK_SHADE0 = 2, TK_EPILOGUE = 9, TK_RESOLVE = 10 }; // tickets[(row * Q_STRIDE + TK_*) * TK_LAUNCH_WORDS]: the counters of one launch of a pass
+enum { TK_EXTEND = 0, TK_CONNECT = 1, TK_SHADE0 = 2, TK_EPILOGUE = 9, TK_RESOLVE = 10, TK_PRESAMPLE = 11 }; // tickets[(row * Q_STRIDE + TK_*) * TK_LAUNCH_WORDS]: the counters of one launch of a pass
 // A round nobody reaches (every path has ended: rounds are enqueued without asking, and for scenes with null-BSDF skips a few more
 // than max_depth + 1) costs its launches only: each kernel looks at the flag and leaves.
 // (Q.alive[row]: the round's "some path is still alive" flag, set by the shade kernels of the round before)
@@ -648,13 +649,14 @@ template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT ==
 #endif
 enum : uint32_t { SH_SOB_WORDS = PTRS_SH_SOB_WORDS, SH_TRI_V4 = PTRS_SH_TRI_V4, SH_LIGHTS = 16, SH_LIGHT_V4 = sizeof(DLight) / 16, SH_TRI_REC_V4 = sizeof(DTriShade) / 16 };
 static_assert(sizeof(DLight) % 16 == 0 && sizeof(DTriShade) % 16 == 0, "records are staged as 16-byte vectors");
-struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds, marg_li; }; // marg_li: the environment light whose marginal tables are staged (0xffffffff: none)
+struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds, marg_li, pre_li; }; // pre_li: the environment light whose samples k_env_presample has left in nee0 / nee1 (0xffffffff: none) // marg_li: the environment light whose marginal tables are staged (0xffffffff: none)
 enum : uint32_t { SH_MARG_N = 1024, SH_MARG_WORDS = 3 * SH_MARG_N + 8 }; // row integrals [nv] | their cdf [nv + 1] | the cdf's guide [guide_v + 1], nv and guide_v <= 1024 // Sobol' window [sob_lo, sob_lo + sob_n), nibbles staged per dimension
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 PT_HD uint32_t sob_stride(uint32_t nib) { return nib * 16u + 4u; } // words per dimension; + 4: consecutive dimensions start 4 banks apart
 struct ShadeCtxLds {
     lds_u32 *sob; lds_v4 *tris, *lights; ShadeLdsCfg cfg; InfMarginal marg;
     __device__ inline const InfMarginal *inf_marginal(uint32_t li) const { return li == cfg.marg_li ? &marg : nullptr; }
+    __device__ inline bool presampled(uint32_t li) const { return li == cfg.pre_li; }
     __device__ inline v4 ld(lds_v4 *q) const { v4 r; r.x = q->x; r.y = q->y; r.z = q->z; r.w = q->w; return r; }
     __device__ inline TriRegs tri(const DScene &sc, int32_t prim, bool want_dp) const {
         if (!cfg.tri_lds) return load_tri_regs(sc.shade + prim, want_dp);
@@ -714,7 +716,8 @@ struct ShadeCtxLds {
 
 template <int MAT, int FEAT>
 __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
-    __shared__ v4 lds_pf[5 * BLOCK]; // the next item's path state per thread, filled by LDS-DMA
+    constexpr uint32_t NPF = (FEAT & FEAT_INFINITE) ? 7u : 5u; // + the vertex's presampled environment-light sample
+    __shared__ v4 lds_pf[NPF * BLOCK]; // the next item's path state per thread, filled by LDS-DMA
     __shared__ uint32_t lds_sob[SH_SOB_WORDS];
     __shared__ v4 lds_tri[SH_TRI_V4];
     __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
@@ -754,6 +757,10 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.beta, p), (lptr *)(lds_pf + (2u * 4u + wv) * 64u), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.st, p), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.hit, p), (lptr *)(lds_pf + (4u * 4u + wv) * 64u), 16, 0, 0);
+        if ((FEAT & FEAT_INFINITE) && cfg.pre_li != 0xffffffffu) {
+            __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.nee0, p), (lptr *)(lds_pf + (5u * 4u + wv) * 64u), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.nee1, p), (lptr *)(lds_pf + (6u * 4u + wv) * 64u), 16, 0, 0);
+        }
     };
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
         const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)s * seg_cap;
@@ -777,6 +784,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
                 const v4 a = X.ld(q + 3 * BLOCK), c = X.ld(q + 4 * BLOCK);
                 in.st.x = f2u(a.x); in.st.y = f2u(a.y); in.st.z = f2u(a.z); in.st.w = f2u(a.w);
                 in.hit.x = f2u(c.x); in.hit.y = f2u(c.y); in.hit.z = f2u(c.z); in.hit.w = f2u(c.w);
+                if ((FEAT & FEAT_INFINITE) && cfg.pre_li != 0xffffffffu) { in.pre0 = X.ld(q + 5 * BLOCK); in.pre1 = X.ld(q + 6 * BLOCK); } else in.pre0 = in.pre1 = mkv4(splat3(0.0f), 0.0f);
             }
             __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS reads are done before the next DMA overwrites the buffer
             const uint32_t i2 = i + 64u;
@@ -811,6 +819,60 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
     { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[11] += t_ - stamp_last; }
     if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&Q.stats[CNT_STAMP0 + k], stamp_acc[k]);
 #endif
+}
+
+// The environment light's samples of a round's vertices, ahead of the round's shade kernels.  Which light a vertex samples and with
+// which numbers is settled by its Sobol' draws alone (light.rs:402-441, integrator.rs:192-217), and for an InfiniteAreaLight the sample's
+// direction, pdf and radiance do not depend on the shading point: a chain of ~8 dependent reads (the marginal walk, the row's guide and
+// cdf, the map's texels) that the shade kernels used to make at 2 waves per SIMD with 250 registers live around it.  Here it runs
+// with a third of the registers and the latency of one vertex hidden behind the others'; the shade kernel receives (wi, pdf | Li, valid)
+// in nee0 / nee1 with the rest of the vertex's state.
+template <int FEAT>
+__global__ __launch_bounds__(BLOCK) void k_env_presample(DSampler S, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t nee_kinds, uint32_t env_li, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
+    __shared__ float lds_marg[SH_MARG_WORDS];
+    __shared__ uint32_t lds_sob[SH_SOB_WORDS]; // the round's Sobol' window in nibble form, as in k_shade (from the global byte tables a draw is four 4-byte gathers out of L2: 12 per vertex here, which made this kernel cost what it saves)
+    if (round_is_dead(Q, it)) return;
+    const DLight &Le = sc.lights[env_li];
+    {
+        const uint32_t stride = sob_stride(cfg.sob_nib), nw = cfg.sob_nib * 16u;
+        for (uint32_t i = threadIdx.x; i < cfg.sob_n * stride; i += BLOCK) { const uint32_t d = i / stride, w = i - d * stride; lds_sob[i] = w < nw ? S.nibtab[((size_t)(cfg.sob_lo + d) * SOBOL_NIBBLES) * 16u + w] : 0u; }
+        const uint32_t nv = (uint32_t)Le.nv, gv = Le.guide_v;
+        for (uint32_t i = threadIdx.x; i < nv; i += BLOCK) lds_marg[i] = sc.distdata[Le.fint_off + i];
+        for (uint32_t i = threadIdx.x; i < nv + 1u; i += BLOCK) lds_marg[SH_MARG_N + i] = sc.distdata[Le.mcdf_off + i];
+        for (uint32_t i = threadIdx.x; i < gv + 1u; i += BLOCK) lds_marg[2u * SH_MARG_N + 1u + i] = sc.distdata[Le.mguide_off + i];
+    }
+    __syncthreads();
+    InfMarginal marg; marg.func = lds_marg; marg.cdf = lds_marg + SH_MARG_N; marg.guide = lds_marg + 2 * SH_MARG_N + 1;
+    ShadeCtxLds X; X.sob = (lds_u32 *)lds_sob; X.tris = nullptr; X.lights = nullptr; X.cfg = cfg; X.marg = marg;
+    const uint32_t lane = __lane_id();
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
+        for (int m = 0; m < 6; ++m) {
+            if (!(nee_kinds & (1u << m))) continue;
+            const uint32_t *__restrict__ queue = Q.mat[m] + (size_t)s * seg_cap;
+            const uint32_t n = rfl(*seg_count(Q, it, Q_MAT0 + m, Gn, s));
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const uint32_t pid = pslot(queue, i);
+                const u4 stv = pslot(P.st, pid);
+                const uint32_t field = f2u(pslot(P.ray_d, pid).w) & ST_DIM_MASK;
+                const VertexDims V = vertex_dims(field, true);
+                const uint64_t index = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
+                const uint32_t dc[1] = {V.nee[4]};
+                float uc[1];
+                X.sobol<1>(S, index, dc, stv.w, uc);
+                const float fl = floor_(uc[0] * (float)sc.n_lights); // the light choice of shade_item
+                uint32_t li = fl > 0.0f ? (uint32_t)fl : 0u;
+                if (li > sc.n_lights - 1u) li = sc.n_lights - 1u;
+                if (li != env_li) continue;
+                const uint32_t dn[2] = {V.nee[0], V.nee[1]};
+                float u[2];
+                X.sobol<2>(S, index, dn, stv.w, u);
+                f3 wi, rgb; float pdf;
+                const bool ok = inf_light_sample(sc, Le, mk2(u[0], u[1]), wi, pdf, rgb, &marg);
+                pslot(P.nee0, pid) = mkv4(wi, pdf);
+                pslot(P.nee1, pid) = mkv4(rgb, u2f(ok ? 1u : 0u));
+            }
+        }
+    }
 }
 
 // totals[row*Q_STRIDE + q] = sum over segments of counts[(row*Q_STRIDE + q)*G + b]; one workgroup per (row, q)
@@ -1243,6 +1305,7 @@ struct HipBackend {
         c.tri_lds = (sc.n_prims * SH_TRI_REC_V4 <= SH_TRI_V4 && opt.shade_lds) ? 1u : 0u;
         c.n_lights_lds = opt.shade_lds ? std::min<uint32_t>(sc.n_lights, SH_LIGHTS) : 0u;
         if (!opt.shade_lds) c.sob_n = 0;
+        c.pre_li = presample_li();
         c.marg_li = 0xffffffffu;
         if (opt.shade_lds && !ps->H.inf_lights.empty()) {
             const DLight &Le = ps->H.lights[ps->H.inf_lights[0]];
@@ -1262,6 +1325,21 @@ struct HipBackend {
         }
     }
     ShadeFn shade_fn(int kind) { return feat == FEAT_SIMPLE ? shade_fn_t<FEAT_SIMPLE>(kind) : (feat == FEAT_IMG ? shade_fn_t<FEAT_IMG>(kind) : (feat == FEAT_IMG_ENV ? shade_fn_t<FEAT_IMG_ENV>(kind) : shade_fn_t<FEAT_FULL>(kind))); }
+    // the environment light k_env_presample serves: one InfiniteAreaLight whose marginal tables fit the LDS area, Sobol' sampler
+    uint32_t presample_li() const {
+        if (!opt.env_presample || !(feat & FEAT_INFINITE) || S.kind != PTRS_SAMPLER_SOBOL || ps->H.inf_lights.empty()) return 0xffffffffu;
+        const DLight &Le = ps->H.lights[ps->H.inf_lights[0]];
+        return (Le.nv >= 1 && (uint32_t)Le.nv <= SH_MARG_N && Le.guide_v >= 1 && Le.guide_v <= SH_MARG_N) ? ps->H.inf_lights[0] : 0xffffffffu;
+    }
+    void presample(uint32_t it) {
+        const uint32_t li = presample_li();
+        const uint32_t nee_kinds = kinds_mask & 0x3fu & ~((1u << PTRS_MAT_MIRROR) | (1u << PTRS_MAT_GLASS));
+        if (li == 0xffffffffu || !nee_kinds) return;
+        t0(T_AUX);
+        if (feat == FEAT_IMG_ENV) hipLaunchKernelGGL((k_env_presample<FEAT_IMG_ENV>), dim3(persistent_grid(k_env_presample<FEAT_IMG_ENV>, T_AUX)), dim3(BLOCK), 0, stream, S, sc, P, Q, it, seg_cap, nee_kinds, li, shade_cfg(it), G, ticket(it, TK_PRESAMPLE));
+        else hipLaunchKernelGGL((k_env_presample<FEAT_FULL>), dim3(persistent_grid(k_env_presample<FEAT_FULL>, T_AUX)), dim3(BLOCK), 0, stream, S, sc, P, Q, it, seg_cap, nee_kinds, li, shade_cfg(it), G, ticket(it, TK_PRESAMPLE));
+        t1();
+    }
     void shade(uint32_t it, int kind) {
         t0(T_SHADE);
         if (kind > 5) kind = 5;

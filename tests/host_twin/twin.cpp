@@ -132,6 +132,7 @@ struct HostBackend {
     }
     void publish_rows(v4 *, int32_t, int32_t) {}
     void dump_rays(uint32_t, const RayDump &) {}
+    void presample(uint32_t) {}
     void export_samples(float *out) {
         for (uint32_t pid = 0; pid < R.n_paths; ++pid) {
             PathCoord c = path_coord(R, S, pid);

@@ -250,6 +250,15 @@ def test_textured_env_matches_oracle(ptrs, orc, scenes):
     _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
 
 
+def test_environment_light_presampling_variants(ptrs, orc, scenes):
+    """The environment light's samples come from k_env_presample (default) or are evaluated inside the shade kernels
+    (env_presample = 0), with the shade kernels' tables in LDS or in global memory: the same samples either way."""
+    for pre, lds in ((0, 1), (1, 0), (0, 0)):
+        with ptrs.options(env_presample=pre, shade_lds=lds):
+            cam, scene = scenes.textured_env((96, 64))
+            _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
+
+
 def test_colonnade_matches_oracle(ptrs, orc, scenes):
     """Sponza-class stand-in (~262k triangles, BVH depth > 16, HBM-resident tree, Disney metal with an
     image texture, directional + point lights) at reduced resolution."""
