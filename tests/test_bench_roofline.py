@@ -1,5 +1,7 @@
 """bench.py's roofline bookkeeping against the committed counter summaries (no GPU): the per-class sums `load_pmc` forms from
-profiles/r02_pmc_<workload>.json and the figures `class_roofline` derives from them."""
+profiles/r03_pmc_<workload>.json, the provenance check (a summary is used only when it carries the hash of the kernel sources
+in this tree) and the figures `class_roofline` derives -- every fraction bounded by 1."""
+import importlib
 import importlib.util
 import json
 import os
@@ -13,21 +15,55 @@ bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 
 
+def _source_hash():
+    return importlib.import_module("pathtracer-rs_amd.build").source_hash()
+
+
 @pytest.mark.parametrize("workload", ["cornell", "colonnade", "classroom"])
 def test_committed_counters_load_and_price(workload):
-    pmc, meta = bench.load_pmc(workload)
-    assert pmc is not None and meta.get("workload") == workload and meta.get("commit")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload)
+    raw = json.load(open(path))
+    h = raw["_meta"]["source_hash"]
+    pmc, meta = bench.load_pmc(workload, h)  # priced as on the tree they were measured on
+    assert pmc is not None and meta["usable"] and meta.get("workload") == workload and meta.get("commit")
     assert {"traversal", "shade"} <= set(pmc)
-    raw = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)))
     trav = [k for k in raw if k.startswith("k_extend") or k.startswith("k_connect")]
-    assert abs(pmc["traversal"]["launches"] - sum(raw[k]["calls"] for k in trav) / max(int(meta.get("frames", 1)), 1)) < 1e-6
-    t = pmc["traversal"]
-    ms = sum(raw[k]["total_ms"] for k in trav)
-    r = bench.class_roofline("traversal", ms, t["launches"], ms, t["launches"], pmc, algorithmic_bytes=1e9)
-    assert r["counters"]["matches_live_launch_count"]
-    assert 0.0 < r["hbm_counter_frac"] < 1.0 and 16.0 < r["lanes_per_valu_inst"] <= 64.0
-    assert 0.0 < r["valu_lane_frac"] < r["valu_issue_frac"] < 1.0
-    assert 0.3 < r["valu_pipe_busy_frac_profiled"] <= 1.0
+    frames = max(int(meta.get("frames", 1)), 1)
+    assert abs(pmc["traversal"]["launches"] - sum(raw[k]["calls"] for k in trav) / frames) < 1e-6
+    for cls in ("traversal", "shade"):
+        c = pmc[cls]
+        ms = c["total_ms"]
+        r = bench.class_roofline(cls, ms, c["launches"], pmc, algorithmic_bytes=1e9 if cls == "traversal" else None)
+        assert r["counters"]["matches_live_launch_count"]
+        lo, hi = r["valu_pipe_frac_lo_hi"]
+        assert 0.0 < lo <= r["valu_pipe_frac"] <= hi < 1.0            # the vector-ALU time the instructions need, against measured issue rates
+        assert 0.0 < r["hbm_counter_frac"] < 1.0 and 16.0 < r["lanes_per_valu_inst"] <= 64.0
+        assert abs(r["wave_issue_frac"] + r["wave_wait_frac"] + r["wave_stall_frac"] - 1.0) < 0.05  # a wave issues, waits in s_waitcnt or waits for a slot
+        assert 0.0 < r["salu_per_valu"] < 1.0
+        assert r["lds_busy_frac"] is None or 0.0 <= r["lds_busy_frac"] < 1.0
+        assert r["bound"] in ("hbm", "valu-issue", "lds", "waitcnt", "mixed")
+        assert r["valu_ceiling_ginst_per_s"] > r["valu_ginst_per_s"]
     # a different launch count means another pipeline: the counters must not be used
-    r2 = bench.class_roofline("traversal", ms, t["launches"] + 2, ms, t["launches"] + 2, pmc)
-    assert not r2["counters"]["matches_live_launch_count"] and "valu_lane_frac" not in r2
+    t = pmc["traversal"]
+    r2 = bench.class_roofline("traversal", t["total_ms"], t["launches"] + 2, pmc)
+    assert not r2["counters"]["matches_live_launch_count"] and "valu_pipe_frac" not in r2
+    # ... and so does a summary measured on other kernel sources
+    none, meta2 = bench.load_pmc(workload, "0123456789abcdef")
+    assert none is None and meta2["usable"] is False and meta2["source_hash"] == h
+
+
+def test_committed_counters_belong_to_this_tree():
+    """The summaries bench.py will use on the GPU box were measured on exactly the kernel sources in this tree (tools/prof.sh records
+    build.source_hash(); a later edit of csrc/ or include/ without re-profiling makes bench.py drop the counters, and this test fail)."""
+    h = _source_hash()
+    for workload in ("cornell", "colonnade", "classroom"):
+        raw = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload)))
+        assert raw["_meta"]["source_hash"] == h, workload
+
+
+def test_valu_ceiling_table_is_the_measured_one():
+    j = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")))
+    best = lambda inst: max(r["per_cycle_per_simd"] for r in j["rows"] if r["inst"] == inst and r["chains"].startswith("8"))
+    assert 0.40 < best("v_fma_f32") < 0.55 and 0.40 < best("v_add_f32") < 0.55          # full-rate class: ~1 per 2.2 cycles and SIMD
+    assert 0.20 < best("v_max_f32") < 0.33 and 0.20 < best("v_cndmask_b32_e64 (mask in an SGPR pair)") < 0.33  # half-rate class
+    assert abs(1.0 / best("v_max_f32") - bench.CLASS_B_CYCLES) < 0.8

@@ -7,8 +7,8 @@ set -x
 OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 tools/bin/valu_ceiling > $OUT/r03_valu_ceiling.json || exit 1
 cp $OUT/r03_valu_ceiling.json profiles/r03_valu_ceiling.json
-for W in cornell colonnade classroom trace-colonnade trace-classroom; do
-  FR=1; case $W in trace-*) FR=3;; esac
+for W in cornell colonnade classroom; do
+  FR=1
   timeout -k 10 900 tools/prof.sh $W fin_$W $FR || exit 1
   cp gpurun_out/prof_fin_$W/pmc.json profiles/r03_pmc_$W.json
   cp gpurun_out/prof_fin_$W/pmc.json $OUT/r03_pmc_$W.json
@@ -19,9 +19,7 @@ done
 timeout -k 10 600 python bench.py > $OUT/r03_bench_cornell.json || exit 1
 timeout -k 10 600 python bench.py --workload colonnade --no-collective-smoke > $OUT/r03_bench_colonnade.json || exit 1
 timeout -k 10 600 python bench.py --workload classroom --no-collective-smoke > $OUT/r03_bench_classroom.json || exit 1
-timeout -k 10 600 python bench.py --workload trace-colonnade --steps 5 > $OUT/r03_bench_trace-colonnade.json || exit 1
-timeout -k 10 600 python bench.py --workload trace-classroom --steps 5 > $OUT/r03_bench_trace-classroom.json || exit 1
-timeout -k 10 600 python bench.py --workload trace-colonnade --steps 5 --node-order 1 > $OUT/r03_bench_trace-colonnade_treelets.json || exit 1
+tools/trace_profiles.sh || exit 1
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/final/r03_bench_*.json")):

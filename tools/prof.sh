@@ -10,6 +10,10 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 CMD="python3 bench.py --workload $W --steps $FR --profile"
+case $W in trace-*) # the ray sets are made by an unprofiled run, so that the profiled processes launch the traced kernel only
+  rm -f /tmp/rays_$W.npz; python3 bench.py --workload $W --rays /tmp/rays_$W.npz > "$OUT/rays.log" 2>&1
+  CMD="$CMD --rays /tmp/rays_$W.npz";;
+esac
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $CMD > "$OUT/kt.log" 2>&1
 cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 i=0
