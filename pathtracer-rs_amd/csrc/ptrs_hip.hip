@@ -421,7 +421,8 @@ __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQu
 // wave time (L2 hit rate 0.47-0.57), so a fifth wave pays even where it costs spills -- the full-feature kernels need 110-122 registers
 // and take 4-14 spilled ones at 96, almost all in the epilogue / resolve code behind the loop: classroom extend 211 -> 197 ms, connect
 // 340 -> 319 ms, frame 923 -> 863 ms.  A sixth wave (80 registers, and only 21 instead of 85 top records in LDS to make room) loses it
-// again: colonnade +3 %, classroom +1 %.  LDS form: 6 (the loop needs 61-76 registers).
+// again: colonnade +3 %, classroom +1 %.  LDS form: 6 (the loop needs 61-76 registers); a 10-entry stack column that spares Cornell's tree
+// (9 entries) the spill code costs the sixth workgroup per CU and 3 % of the extension kernel.
 #ifndef PTRS_QUAD_WAVES
 #define PTRS_QUAD_WAVES 5
 #endif
@@ -619,14 +620,15 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
 
 
 // One instantiation per material kind (and feature set): lobe kinds are compile-time constants.
-// Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X.  The Matte / FEAT_SIMPLE kernel needs 183
-// registers unconstrained and fits 168 (3 waves) with 24 bytes of scratch: +1.6 % on the Cornell frame together with the
-// smaller LDS tables below (three workgroups per CU instead of two).  The mirror / glass kernels need 109-135 registers and
-// get their third wave from the LDS budget alone; the Disney kernel with image textures (colonnade) needs 209 and still gains at
-// 168 with 112 bytes of scratch (shade kernels 39.2 -> 37.2 ms, frame +1.9 %); the other Disney / metal / substrate kernels
-// (191-256 registers) stay at 2, unmeasured or measured worse.
+// Occupancy hint (waves per SIMD) per instantiation, from A/B runs on MI355X.  The Matte / FEAT_SIMPLE kernel needs 197 registers:
+// round 2 ran it at 3 waves (168 registers, 24 bytes of scratch, +1.6 % on the Cornell frame); with this round's wave-per-segment
+// loop around it 168 registers cost 24 spilled ones (116 bytes of scratch, each reload a trip to L1 / L2 that 2.7 waves per SIMD do
+// not cover), and at 2 waves without spills the kernel is 2 % faster alone and the three-lane frame 5 % (177.9-179.2 -> 169.3-169.8
+// ms: its workgroups leave room for the other lanes' traversal kernels).  The mirror / glass kernels need 109-135 registers and get
+// their third wave from the LDS budget alone; the Disney kernel with image textures (colonnade) needs 209 and still gains at 168
+// with spills (shade kernels 42.3 -> 39.6 ms); the other Disney / metal / substrate kernels (191-256 registers) stay at 2.
 #ifndef PTRS_SHADE_WAVES_MATTE
-#define PTRS_SHADE_WAVES_MATTE 3
+#define PTRS_SHADE_WAVES_MATTE 2
 #endif
 #ifndef PTRS_SHADE_WAVES_DISNEY_IMG
 #define PTRS_SHADE_WAVES_DISNEY_IMG 3
