@@ -228,17 +228,20 @@ enum {
 
 typedef struct PtrsScene PtrsScene;
 
-/* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-4 concurrent
- * pipeline lanes, default 3), "refill" / "refill_connect" (idle-lane threshold of the lane-refill traversal
- * kernels, 0 = fused kernels, -1 = by scene), "vote" (phase voting in the lane-refill
- * traversal kernels: 0 off, 1 on, 2 extension kernel only, -1 = by scene), "stack_lds" (8 or 16 LDS stack
- * entries per lane), "grid_mult", "shade_lds" (0/1: shade kernels read their small tables from LDS),
- * "fused_epilogue" / "fused_resolve" (0/1: the traversal kernels run the segment's epilogue / MIS resolve
- * behind their last ray instead of separate k_epilogue / k_resolve launches), "node_form" (0 auto, 2 force
- * quad nodes), "workspace_pct" (share of the free device memory the render workspace may take, default
- * 40).  None of them changes a result bit; they select between equivalent schedules.  Scene-level knobs
- * (node_form, stack_lds, grid_mult) are read by ptrs_scene_create, the rest by each render call.
- * Replaces nothing in the reference (its only knobs are the CLI flags of main.rs:36-52). */
+/* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-4 concurrent pipeline lanes;
+ * 0 = by the size of the job: one when the frame fits one pass, else three), "grid_mult" (queue segments -- one wave each -- per
+ * pass = CUs x 8 x grid_mult, default 8), "grid_pct" (share of its resident capacity a persistent launch takes; 0 = 50 with
+ * several lanes, 100 with one), "persist" (0/1), "whole_rounds" (0/1), "refill" / "refill_connect" (idle-lane threshold of the
+ * lane-refill traversal kernels, 0 = refill only when the whole wave is idle, -1 = by scene), "vote" (phase voting in the traversal
+ * kernels: 0 off, 1 on, 2 extension kernel only, -1 = by scene), "stack_lds" (8 or 16 LDS stack entries per lane), "shade_lds"
+ * (0/1: shade kernels read their small tables from LDS), "env_presample" (0/1: environment-light samples evaluated ahead of the
+ * shade kernels), "fused_epilogue" / "fused_resolve" (0/1: the traversal kernels run the segment's epilogue / MIS resolve behind
+ * the wave's last ray instead of separate k_epilogue / k_resolve launches), "node_form" (0 auto, 2 force quad nodes), "node_order"
+ * (0 / 1: quad-node order behind the LDS-cached top), "workspace_pct" (share of the free device memory the render workspace may
+ * take, default 40), "peer_copy" (0: ptrs_render_multi stages bands through the host film).  None of them changes a result bit;
+ * they select between equivalent schedules.  Scene-level knobs (node_form, node_order, stack_lds) are read by
+ * ptrs_scene_create, the rest by each render call.  Replaces nothing in the reference (its only knobs are the CLI flags of
+ * main.rs:36-52). */
 int ptrs_set_option(const char *name, int64_t value);
 int ptrs_get_option(const char *name, int64_t *value);
 /* The same knobs for ONE scene: its renders take this value instead of the process-wide one (two embedders in a process, or

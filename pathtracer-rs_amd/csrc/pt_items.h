@@ -382,12 +382,12 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     }
     // ---- the vertex's stores ------------------------------------------------------------------------------------------
     X.before_stores();
-    if (out.shadow) { pslot(P.sh_o, pid) = w_sh_o; pslot(P.sh_d, pid) = w_sh_d; }
-    if (out.mis) { pslot(P.mis_o, pid) = w_mis_o; pslot(P.mis_d, pid) = w_mis_d; }
-    if (out.mis) { pslot(P.nee0, pid) = w_nee0; pslot(P.nee1, pid) = w_nee1; pslot(P.nee2, pid) = w_nee2; } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1 / nee2)
+    if (out.shadow) { pstore(P.sh_o, pid, w_sh_o); pstore(P.sh_d, pid, w_sh_d); }
+    if (out.mis) { pstore(P.mis_o, pid, w_mis_o); pstore(P.mis_d, pid, w_mis_d); }
+    if (out.mis) { pstore(P.nee0, pid, w_nee0); pstore(P.nee1, pid, w_nee1); pstore(P.nee2, pid, w_nee2); } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1 / nee2)
     if (w_pre) { if (out.next) w_ro.w = w_cz; else reinterpret_cast<float *>(&pslot(P.ray_o, pid))[3] = w_cz; }
-    if (w_skip) { pslot(P.ray_o, pid) = w_ro; pslot(P.ray_d, pid) = mkv4(rd, u2f(w_stz)); out.next = true; }
-    else if (out.next) { pslot(P.ray_o, pid) = w_ro; pslot(P.ray_d, pid) = w_rd; pslot(P.beta, pid) = w_beta; }
+    if (w_skip) { pstore(P.ray_o, pid, w_ro); pstore(P.ray_d, pid, mkv4(rd, u2f(w_stz))); out.next = true; }
+    else if (out.next) { pstore(P.ray_o, pid, w_ro); pstore(P.ray_d, pid, w_rd); pstore(P.beta, pid, w_beta); }
     PT_STAMP(8, 0u)
     return out;
 }

@@ -1,11 +1,12 @@
 // ptrs_hip.hip -- gfx950 (MI355X) kernels and the C ABI of include/ptrs.h.
 //
-// One wavefront stage = one kernel.  Every queue-driven kernel is launched with a fixed persistent
-// grid (CUs x 8 workgroups of 256 threads = 4 wave64 per workgroup) and grid-strides over a queue
-// whose length it reads from device memory, so a whole pass is enqueued without host round trips.
-// Queues are segmented per workgroup; slots come from LDS counters (one ds_add per wave), never from global atomics.
-// The traversal stack lives in LDS, one column of 8-byte (node ref, entry distance) records per lane; on
-// trees deeper than the LDS column the excess spills to a per-thread column in global memory.
+// One wavefront stage = one kernel.  Every queue-driven kernel is PERSISTENT: a launch holds the workgroups that fit the machine at
+// once (256 threads = 4 wave64 each), and each WAVE works through queue segments -- one wave per segment -- that it takes from the
+// launch's ticket counters until none is left; segment lengths are read from device memory, so a whole pass is enqueued without
+// host round trips.  Slots in the segment a wave appends to come from a counter in a scalar register of that wave: no LDS or
+// global atomics on the data path, no workgroup barrier behind the staging of the read-only tables.
+// The traversal stack lives in LDS, one column of 8-byte (node ref, entry distance) records per lane; on trees deeper than the LDS
+// column the excess spills to a per-thread column in global memory.  Small scenes live in LDS entirely, resolved by ray class.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (bit-exact arithmetic, see pt_vec.h).
 #include <hip/hip_runtime.h>
