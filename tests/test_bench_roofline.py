@@ -65,5 +65,7 @@ def test_valu_ceiling_table_is_the_measured_one():
     j = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")))
     best = lambda inst: max(r["per_cycle_per_simd"] for r in j["rows"] if r["inst"] == inst and r["chains"].startswith("8"))
     assert 0.40 < best("v_fma_f32") < 0.55 and 0.40 < best("v_add_f32") < 0.55          # full-rate class: ~1 per 2.2 cycles and SIMD
-    assert 0.20 < best("v_max_f32") < 0.33 and 0.20 < best("v_cndmask_b32_e64 (mask in an SGPR pair)") < 0.33  # half-rate class
-    assert abs(1.0 / best("v_max_f32") - bench.CLASS_B_CYCLES) < 0.8
+    assert 0.20 < best("v_max_f32") < 0.36 and 0.20 < best("v_cndmask_b32_e64 (mask in an SGPR pair)") < 0.36  # half-rate class (0.24 at 2-6 waves, up to 0.32 at 8)
+    at4 = lambda inst: next(r["per_cycle_per_simd"] for r in j["rows"] if r["inst"] == inst and r["chains"].startswith("8") and r["waves_per_simd"] == 4)
+    assert abs(1.0 / at4("v_max_f32") - bench.CLASS_B_CYCLES) < 0.5 and abs(1.0 / at4("v_cmp_lt_f32_e64 -> SGPR pair") - bench.CLASS_B_CYCLES) < 0.5  # the model's 4.2 cycles: the rate at 2-6 waves per SIMD
+    assert at4("mix v_max_f32 : v_fma_f32 = 1 : 1") > 0.38  # the two classes issue side by side
