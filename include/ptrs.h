@@ -219,6 +219,8 @@ typedef struct PtrsStats {
     uint64_t resident_wgs_per_cu[4];
     uint64_t lanes;          /* pipeline lanes the call ran on (option "lanes", or chosen by the size of the job) */
     uint64_t grid_pct;       /* share of a kernel's resident capacity its launches took (option "grid_pct", or chosen with the lanes) */
+    double ms_enqueue;       /* host time from the start of the call until its last pass was enqueued (a job of more passes than lanes
+                              * waits for a lane in between); ms_total - ms_enqueue is what the host then waited for the device */
 } PtrsStats;
 
 enum {
@@ -228,10 +230,10 @@ enum {
 
 typedef struct PtrsScene PtrsScene;
 
-/* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-4 concurrent pipeline lanes;
- * 0 = by the size of the job: one when the frame fits one pass, else three), "grid_mult" (queue segments -- one wave each -- per
- * pass = CUs x 8 x grid_mult, default 8), "grid_pct" (share of its resident capacity a persistent launch takes; 0 = 50 with
- * several lanes, 100 with one), "persist" (0/1), "whole_rounds" (0/1), "refill" / "refill_connect" (idle-lane threshold of the
+/* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-8 concurrent pipeline lanes;
+ * 0 = four, one for a job under 4 M paths), "grid_mult" (queue segments -- one wave each -- per pass = CUs x 8 x grid_mult; 0 = 1
+ * with several lanes, 8 with one), "grid_pct" (share of its resident capacity a persistent launch takes; 0 = 100, or 50 with several
+ * lanes and a grid_mult given by hand), "persist" (0/1), "whole_rounds" (0/1), "refill" / "refill_connect" (idle-lane threshold of the
  * lane-refill traversal kernels, 0 = refill only when the whole wave is idle, -1 = by scene), "vote" (phase voting in the traversal
  * kernels: 0 off, 1 on, 2 extension kernel only, -1 = by scene), "stack_lds" (8 or 16 LDS stack entries per lane), "shade_lds"
  * (0/1: shade kernels read their small tables from LDS), "env_presample" (0/1: environment-light samples evaluated ahead of the

@@ -324,6 +324,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             if (!spare_rounds) close_pass(lane); // nothing to ask: the film kernel follows the rounds at once
         }
     }
+    st.ms_enqueue = std::chrono::duration<double, std::milli>(clock::now() - t_begin).count();
     for (uint32_t k = 0; k < n_lanes; ++k) finish((pass_no + k) % n_lanes); // oldest pass first: the callbacks keep their order
     be.end(st);
     if (null_skip_overrun) st.error_flags |= PTRS_ERRFLAG_NULL_SKIPS;

@@ -41,8 +41,8 @@ struct Options {
     int refill = -1;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend; -1 = by scene (32 with phase voting and no alpha masks, else 16)
     int refill_connect = -1;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
-    int grid_mult = 8;        // queue segments (one wave each) per pass: CUs x 8 x grid_mult, i.e. 16384 on MI355X at the default (Cornell single-lane frame: 4: 252 ms, 8: 216, 16: 222)
-    int grid_pct = 0;         // share of its resident capacity a persistent launch takes: below 100 a kernel leaves wave slots to the kernels of the other pipeline lanes; 0 = 50 with several lanes, 100 with one
+    int grid_mult = 0;        // queue segments (one wave each) per pass: CUs x 8 x grid_mult; 0 = 1 with several lanes (2 048 on MI355X), 8 with one (16 384; Cornell single-lane frame at 4 / 8 / 16: 252 / 216 / 222 ms)
+    int grid_pct = 0;         // share of its resident capacity a persistent launch takes: below 100 a kernel leaves wave slots to the kernels of the other pipeline lanes; 0 = 100 (50 with several lanes and a grid_mult given by hand)
     int whole_rounds = 0;     // 1: segments per pass rounded to a whole multiple of the traversal kernels' resident waves (HipBackend::whole_rounds); measured within noise of 0 (exactly CUs x 8 x grid_mult) on Cornell / classroom, 2.5 % slower on colonnade
     int persist = 1;          // queue kernels are launched with the workgroups that fit the machine at once (occupancy x CUs); 0: with 8 per CU, the hardware's maximum (A/B hook)
     int node_form = 0;        // 0 = by size, 2 = quad nodes also for scenes that would fit LDS (test hook)
@@ -62,8 +62,8 @@ std::mutex g_opt_mu;
 Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
-    {"lanes", &Options::lanes, 0, 4}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 1, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1}, {"env_presample", &Options::env_presample, 0, 1},
+    {"lanes", &Options::lanes, 0, 8}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
+    {"grid_mult", &Options::grid_mult, 0, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1}, {"env_presample", &Options::env_presample, 0, 1},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -1053,7 +1053,7 @@ int get_sobol(int device, SobolDevice **out) {
 
 } // namespace
 
-enum { MAX_LANES = 4 };
+enum { MAX_LANES = 8 };
 struct PtrsScene {
     int device = 0;
     HostScene H; // host copy kept for validation / stats
@@ -1096,22 +1096,23 @@ struct HipBackend {
     uint32_t G = 1, seg_cap = 0;  // segmented queues of the current pass
     // pipeline lanes: the members above (stream, R, P, Q, G, seg_cap) are those of the selected lane
     struct Lane { hipStream_t stream; DParams R; DPaths P; DQueues Q; uint32_t G, seg_cap; };
-    Lane lane_[MAX_LANES]; uint32_t n_lanes = 3, cur = 0; // measured on Cornell: 1 lane 5376, 2: 6395, 3: 6578, 4: 6618 Mray/s
+    Lane lane_[MAX_LANES]; uint32_t n_lanes = 1, cur = 0;
     hipEvent_t film_prev = nullptr;
     Options opt;
-    // Pipeline lanes of this render (called before begin()).  lanes = 0: by the size of the job -- a frame that fits one pass runs on one
-    // lane (its kernels are as long as they can be; measured on colonnade, 59 M paths: 1 lane 119 ms, 3 lanes 135 ms), a longer one on
-    // three, whose kernels then take half of their resident capacity each (grid_pct) so that a traversal kernel and a shade kernel of
-    // two lanes share the CUs (Cornell, 271 M paths: 1 lane 192 ms, 3 lanes 176 ms, 3 lanes at half capacity 169 ms).
-    uint32_t lanes(uint64_t job_paths = 0, const bool *kinds = nullptr) {
+    // Pipeline lanes of this render and the size of its launches (called before begin()).  Defaults (lanes = grid_mult = grid_pct = 0):
+    // FOUR lanes whose passes have 2 048 segments each (grid_mult 1): a queue kernel then holds 2 048 waves, a third of the machine's
+    // slots, for its whole run, and the kernels of the four lanes -- traversal and shade kernels of different passes, with their
+    // different appetites for registers, LDS and memory -- fill the CUs together all the time.  Measured against this round's other
+    // arrangements on one box: Cornell 161.2-161.6 ms (three lanes with 16 384 segments at half the resident capacity each: 169.2;
+    // one lane: 192), colonnade 114.9 (one lane with 16 384 segments: 116.9), classroom 847-852 (852); five and more lanes are
+    // slower (182 / 174 / 167 ms for 5 / 6 / 8 on Cornell: the runtime maps streams onto four hardware queues).  A job too small to
+    // give four lanes a pass each runs on one lane with 16 384 segments, and so does every single-lane render (the profiled frames).
+    uint32_t lanes(uint64_t job_paths = 0, const bool * = nullptr) {
         int want = opt.lanes;
-        if (want == 0) {
-            const bool none[7] = {false, false, false, false, false, false, false};
-            const uint64_t one_pass = std::min<uint64_t>(1ull << 27, auto_capacity(1, kinds ? kinds : none));
-            want = job_paths <= one_pass ? 1 : 3;
-        }
+        if (want == 0) want = job_paths >= (4ull << 20) ? 4 : 1;
         n_lanes = (uint32_t)(want < 1 ? 1 : (want > MAX_LANES ? MAX_LANES : want));
-        if (opt.grid_pct == 0) opt.grid_pct = n_lanes > 1 ? 50 : 100;
+        if (opt.grid_mult == 0) { opt.grid_mult = n_lanes > 1 ? 1 : 8; if (opt.grid_pct == 0) opt.grid_pct = 100; }
+        if (opt.grid_pct == 0) opt.grid_pct = n_lanes > 1 ? 50 : 100; // (several lanes with many segments each: a launch takes half of its resident capacity)
         return n_lanes;
     }
     void select(uint32_t l) {
@@ -1219,7 +1220,7 @@ struct HipBackend {
         refill_connect = (uint32_t)(opt.refill_connect > 0 ? opt.refill_connect : (opt.refill_connect == 0 ? 64 : ((vote_connect && feat_trace == FEAT_SIMPLE) ? 32 : 16)));
         geom4 = sc.n_nodes4 ? 0xffffffffu : LN_V4 * sc.n_nodes2 + 9u * sc.n_prims; // quad form: global kernels; pair form: fits the LDS staging area by construction (pt_host_scene.h)
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) kinds_mask |= 1u << k;
-        grid_max = ps->n_cu * 8 * opt.grid_mult;
+        grid_max = ps->n_cu * 8 * (opt.grid_mult ? opt.grid_mult : 8);
         if (opt.persist && opt.whole_rounds) grid_max = (int)(feat_trace == FEAT_FULL ? whole_rounds<FEAT_FULL>((uint32_t)grid_max) : (feat_trace == FEAT_IMG_ENV ? whole_rounds<FEAT_IMG_ENV>((uint32_t)grid_max) : whole_rounds<FEAT_SIMPLE>((uint32_t)grid_max)));
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + ((size_t)grid_max + 1) * 64) * 4; // queues: G segments of whole 64-entry chunks
         if ((rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
@@ -1428,6 +1429,7 @@ int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm,
     HIPCHK(hipSetDevice(ps->device));
     HipBackend be;
     be.ps = ps; be.stream = stream; be.opt = scene_options(ps); be.host_film = host_film; be.film_w = prm->width; be.share = share;
+    if (dump && be.opt.lanes == 0) be.opt.lanes = 1; // a ray dump is of the render's first pass: one lane gives that pass as many of the job's paths as memory holds
     int rc = get_sobol(ps->device, &be.sob);
     if (rc != PTRS_OK) return rc;
     std::string err;
@@ -1814,7 +1816,7 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
         be.vote = be.opt.vote >= 0 ? be.opt.vote != 0 : true;
         be.refill = (uint32_t)(be.opt.refill > 0 ? be.opt.refill : (be.opt.refill == 0 ? 64 : ((be.vote && be.feat_trace == FEAT_SIMPLE) ? 32 : 16)));
         be.geom4 = be.sc.n_nodes4 ? 0xffffffffu : LN_V4 * be.sc.n_nodes2 + 9u * be.sc.n_prims;
-        const uint32_t chunks = (n + 63u) / 64u, gmax = (uint32_t)scene->n_cu * 8u * (uint32_t)be.opt.grid_mult;
+        const uint32_t chunks = (n + 63u) / 64u, gmax = (uint32_t)scene->n_cu * 8u * (uint32_t)(be.opt.grid_mult ? be.opt.grid_mult : 8); // (one launch at a time: the single-lane segmentation)
         const uint32_t G = chunks < gmax ? chunks : gmax, seg_cap = ((chunks + G - 1) / G) * 64u;
         be.G = G; be.seg_cap = seg_cap;
         std::vector<v4> ro(n), rd(n);

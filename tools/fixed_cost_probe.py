@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Frame time against job size on one GPU (Cornell, 256 spp, row bands of growing height): the intercept is what a render call costs
+before and after its kernels.  python tools/fixed_cost_probe.py"""
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+pkg = importlib.import_module("pathtracer-rs_amd")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cam, scene = pkg.import_scene(os.path.join(root, "data", "cornell-box.xml"), (1024, 1024))
+integ = pkg.PathIntegrator(pkg.SamplerBuilder(256, cam.film.get_sample_bounds()), 15)
+film = torch.zeros((1024, 1024, 4), dtype=torch.float32, device="cuda")
+integ.render_device(cam, scene, film.data_ptr(), stream=0)  # workspace for the largest job
+for rows in (1, 4, 16, 64, 128, 256, 512, 1024):
+    ts = []
+    for k in range(4):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        st = integ.render_device(cam, scene, film.data_ptr(), stream=0, row_begin=448, row_end=448 + rows) if rows < 1024 else integ.render_device(cam, scene, film.data_ptr(), stream=0)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    print("rows %4d: %7.2f ms (min of 3 after a warm-up; %5.1f ms per 128 rows), lanes %d, segments %d, passes %d" % (rows, min(ts[1:]) * 1e3, min(ts[1:]) * 1e3 * 128 / rows, st.lanes, st.queue_segments, st.passes))
