@@ -530,6 +530,8 @@ def main():
                        "band_probe_ms": probe_ms, "value_incl_band_probe": rays / (dt + args.steps * probe_ms * 1e-3) / 1e6,  # a host that plans its bands per frame pays the probe per frame
                        "collective": ("none" if world == 1 else ("rccl gather of film row bands" if backend == "nccl" else backend + " gather (host-staged fallback, NOT an RCCL number)")),
                        "halo_overhead": rows_traced / float(H + 4) - 1.0, "rays_traced_incl_halo_per_step": rays_traced / args.steps,
+                       "rays_by_kind_rank0_per_step": {"extension (closest hit; one per path vertex reached)": int(st.rays_extension), "shadow (any hit)": int(st.rays_shadow), "mis (closest hit)": int(st.rays_mis)},
+                       "host_enqueue_ms_per_step": st.ms_enqueue,
                        "pipeline_lanes": int(st.lanes), "launch_share_of_resident_capacity_pct": int(st.grid_pct), "timed_path": "library default (no PTRS_FLAG_TIMING)",
                        "launch": {"queue_segments_per_pass": st.queue_segments, "passes_per_frame": st.passes, "kernel_launches_per_frame": st.kernel_launches,
                                   "workgroups_last_launch": dict(zip(("extend", "connect", "shade", "aux"), [int(x) for x in st.grid_wgs])),

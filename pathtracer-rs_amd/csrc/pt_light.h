@@ -106,47 +106,52 @@ PT_HD bool inf_light_sample(const DScene &sc, const DLight &L, f2 u, f3 &wi, flo
     float d0 = dist1d_sample(D + L.func_off + (uint64_t)v * (uint32_t)L.nu, D + L.cdf_off + (uint64_t)v * ((uint32_t)L.nu + 1u), mf[v], (uint32_t)L.nu, u.x, pdf_u, dummy,
                              D + L.cguide_off + (uint64_t)v * (L.guide_u + 1u), L.guide_u);
     float map_pdf = pdf_u * pdf_v;
-    if (map_pdf == 0.0f) { li = splat3(0.0f); pdf = 0.0f; wi = splat3(0.0f); return false; }
-    float theta = d1 * PT_PI, phi = d0 * 2.0f * PT_PI;
-    float ct, st, sp, cp; pt_sincosf(theta, &st, &ct); pt_sincosf(phi, &sp, &cp);
-    wi = xform_vec(L.l2w, mk3(st * cp, st * sp, ct));
-    pdf = st == 0.0f ? 0.0f : map_pdf / (2.0f * PT_PI * PT_PI * st);
-    li = env_lookup(sc, L, mk2(d0, d1));
-    return true;
+    f3 li_ = splat3(0.0f), wi_ = splat3(0.0f); float pdf_ = 0.0f; // (one exit, the outputs assigned there: see light_sample_li)
+    const bool ok = map_pdf != 0.0f;
+    if (ok) {
+        float theta = d1 * PT_PI, phi = d0 * 2.0f * PT_PI;
+        float ct, st, sp, cp; pt_sincosf(theta, &st, &ct); pt_sincosf(phi, &sp, &cp);
+        wi_ = xform_vec(L.l2w, mk3(st * cp, st * sp, ct));
+        pdf_ = st == 0.0f ? 0.0f : map_pdf / (2.0f * PT_PI * PT_PI * st);
+        li_ = env_lookup(sc, L, mk2(d0, d1));
+    }
+    li = li_; pdf = pdf_; wi = wi_;
+    return ok;
 }
 
 // Light::sample_li.  Returns false when the reference leaves the visibility tester unset
 // (InfiniteAreaLight with map_pdf == 0, light.rs:411-413) -- the reference would panic there.
 template <int FEAT>
 PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const SpawnPair &ref_sp, f2 u, LightSample &o, const InfMarginal *im = nullptr) {
-    o.p1_err = splat3(0.0f); o.p1_n = splat3(0.0f);
+    // (one exit, every field of `o` assigned there from locals: with a return per light kind the optimizer merged the kinds' stores of
+    // different fields behind a pointer phi, which kept four floats of the sample in scratch memory -- 20 bytes per lane that cost
+    // every launch of a shade kernel its scratch set-up)
+    f3 li = splat3(0.0f), wi = splat3(0.0f), p1 = ref_p, p1_err = splat3(0.0f), p1_n = splat3(0.0f);
+    float pdf = 0.0f;
+    bool ok = true;
     if (L.kind == 0) { // point
         f3 pl = ld3(L.v);
-        o.wi = normalize(pl - ref_p); o.pdf = 1.0f; o.p1 = pl;
-        o.li = ld3(L.c) / len2(pl - ref_p);
-        return true;
-    }
-    if (L.kind == 1) { // directional
+        wi = normalize(pl - ref_p); pdf = 1.0f; p1 = pl;
+        li = ld3(L.c) / len2(pl - ref_p);
+    } else if (L.kind == 1) { // directional
         f3 w = ld3(L.v);
-        o.wi = w; o.pdf = 1.0f; o.p1 = ref_p + w * (2.0f * L.world_radius);
-        o.li = ld3(L.c);
-        return true;
-    }
-    if (L.kind == 2) { // diffuse area light on one triangle (its record is embedded in the light)
+        wi = w; pdf = 1.0f; p1 = ref_p + w * (2.0f * L.world_radius);
+        li = ld3(L.c);
+    } else if (L.kind == 2) { // diffuse area light on one triangle (its record is embedded in the light)
         const TriRegs T = load_tri_regs(&L.T);
         f3 p, n, perr; f2 uv;
         tri_sample(T, u, p, n, perr, uv, L.n_ok ? L.n_sample : nullptr);
-        o.wi = normalize(p - ref_p);
-        o.pdf = tri_pdf_at_point<FEAT>(sc, T, L.area, ref_p, ref_sp, o.wi, L.n_ok ? L.n_point : nullptr);
-        o.p1 = p; o.p1_err = perr; o.p1_n = n;
-        f3 w = -o.wi;
-        o.li = dot(n, w) > 0.0f ? (L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f)) : splat3(0.0f);
-        return true;
+        wi = normalize(p - ref_p);
+        pdf = tri_pdf_at_point<FEAT>(sc, T, L.area, ref_p, ref_sp, wi, L.n_ok ? L.n_point : nullptr);
+        p1 = p; p1_err = perr; p1_n = n;
+        f3 w = -wi;
+        li = dot(n, w) > 0.0f ? (L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f)) : splat3(0.0f);
+    } else if (!(FEAT & FEAT_INFINITE)) { ok = false; // unreachable
+    } else { // infinite area light
+        ok = inf_light_sample(sc, L, u, wi, pdf, li, im);
+        p1 = ok ? ref_p + wi * (2.0f * L.world_radius) : ref_p;
     }
-    if (!(FEAT & FEAT_INFINITE)) { o.li = splat3(0.0f); o.pdf = 0.0f; o.wi = splat3(0.0f); o.p1 = ref_p; return false; } // unreachable
-    // infinite area light
-    const bool ok = inf_light_sample(sc, L, u, o.wi, o.pdf, o.li, im);
-    o.p1 = ok ? ref_p + o.wi * (2.0f * L.world_radius) : ref_p;
+    o.li = li; o.wi = wi; o.pdf = pdf; o.p1 = p1; o.p1_err = p1_err; o.p1_n = p1_n;
     return ok;
 }
 

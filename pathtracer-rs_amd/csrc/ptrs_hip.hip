@@ -507,13 +507,13 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
         uint32_t cursor = 0;
         bool has = false, shadow_phase = false, setup = false;
         uint32_t pid = 0, fl = 0;
-        v4 pre_c, pre_l; pre_c.x = pre_c.y = pre_c.z = pre_c.w = 0.0f; pre_l = pre_c; // NEE_PRE records: the contribution and the path's radiance, fetched with the ray
+        f3 pre_l = splat3(0.0f); // NEE_PRE records: the path's radiance WITH the record's contribution (both fetched with the ray, added at once: three registers live across the traversal instead of seven), stored if the ray comes through
         RF_DECL LF_DECL // (per segment: nothing of a ray is live across the resolve)
         for (;;) {
             if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
                 if (shadow_phase) {
                     if (fl & NEE_PRE) { // a shadow-only record is resolved here: l += beta * nLights * ld unless the ray was blocked (integrator.rs:66-78, 444-446)
-                        if (!r_hit) { v4 o = pre_l; o.x = pre_l.x + pre_c.x; o.y = pre_l.y + pre_c.y; o.z = pre_l.z + pre_c.z; pslot(P.L, pid) = o; }
+                        if (!r_hit) pslot(P.L, pid) = mkv4(pre_l, 0.0f); // (L.w is never anything but generate_item's 0)
                         has = false;
                     } else {
                         if (r_hit) reinterpret_cast<uint32_t *>(&pslot(P.nee2, pid))[3] |= NEE_OCCLUDED << 24;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             if (batch && setup) {
                 const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
                 const v4 o = pslot(po, pid), d = pslot(pd, pid);
-                if (shadow_phase && (fl & NEE_PRE)) { pre_c.x = d.w; pre_c.y = o.w; pre_c.z = reinterpret_cast<const float *>(&pslot(P.ray_o, pid))[3]; pre_l = pslot(P.L, pid); } // shade_item's packing of a shadow-only record
+                if (shadow_phase && (fl & NEE_PRE)) { const f3 c = mk3(d.w, o.w, reinterpret_cast<const float *>(&pslot(P.ray_o, pid))[3]); pre_l = xyz(pslot(P.L, pid)) + c; } // shade_item's packing of a shadow-only record; resolve_item's sum
                 if (GEOM > 0) LF_START(LG, xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF) else RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
                 stk.clear(); setup = false;
             }

@@ -16,12 +16,15 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cam, scene = pkg.import_scene(os.path.join(root, "data", "cornell-box.xml"), (1024, 1024))
 integ = pkg.PathIntegrator(pkg.SamplerBuilder(256, cam.film.get_sample_bounds()), 15)
 film = torch.zeros((1024, 1024, 4), dtype=torch.float32, device="cuda")
+timing = bool(int(os.environ.get("TIMING", "0")))  # TIMING=1: an event pair around every launch; the per-class sums say whether the kernels of a small job are slower or the device idles between them
+row0 = 0 if rows >= 1024 else 448
+abi = importlib.import_module("pathtracer-rs_amd.abi")
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 if passes:
-    st = integ.render_device(cam, scene, film.data_ptr(), stream=0, row_begin=448, row_end=448 + rows)
+    st = integ.render_device(cam, scene, film.data_ptr(), stream=0, row_begin=row0, row_end=row0 + rows, flags=abi.FLAG_TIMING if timing else 0)
     per_spp = st.samples // 256
     integ.paths_per_pass = per_spp * ((256 + passes - 1) // passes)
 for k in range(n):
     torch.cuda.synchronize(); t = time.perf_counter()
-    st = integ.render_device(cam, scene, film.data_ptr(), stream=0, row_begin=448, row_end=448 + rows)
-    torch.cuda.synchronize(); print("call %d: %.2f ms (library: total %.2f, enqueue %.2f; %d launches, %d lanes, %d passes)" % (k, (time.perf_counter() - t) * 1e3, st.ms_total, st.ms_enqueue, st.kernel_launches, st.lanes, st.passes))
+    st = integ.render_device(cam, scene, film.data_ptr(), stream=0, row_begin=row0, row_end=row0 + rows, flags=abi.FLAG_TIMING if timing else 0)
+    torch.cuda.synchronize(); print("call %d: %.2f ms (library: total %.2f, enqueue %.2f; %d launches, %d lanes, %d passes)" % (k, (time.perf_counter() - t) * 1e3, st.ms_total, st.ms_enqueue, st.kernel_launches, st.lanes, st.passes) + ("; kernel sums: extend %.2f connect %.2f shade %.2f aux %.2f film %.2f ms" % (st.ms_extend, st.ms_connect, st.ms_shade_kernels, st.ms_aux, st.ms_film) if timing else ""))
