@@ -55,7 +55,7 @@ PT_HD PathCoord path_coord(const DParams &R, const DSampler &S, uint32_t pid) {
 
 PT_HD uint32_t strat_pack(uint32_t d1, uint32_t d2) { return (d1 & 63u) | ((d2 & 63u) << 6); } // the stratified sampler's 1-D / 2-D dimension counters in the state word's dimension field
 
-PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, const DPaths &P, uint32_t pid) {
+PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, const DPaths &P, uint32_t pid, uint32_t e) { // e: the path's position in round 0's extension queue
     PathCoord c = path_coord(R, S, pid);
     f2 u; u4 st;
     if (S.kind == PTRS_SAMPLER_STRATIFIED) { // get_camera_sample = the first 2-D dimension of the pixel's table (mod.rs:156-160)
@@ -72,10 +72,10 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
     }
     f2 pf = mk2((float)c.px + u.x, (float)c.py + u.y);
     CamRay r = camera_ray(C, pf, R.inv_sqrt_spp);
-    pslot(P.ray_o, pid) = mkv4(r.o, PT_INF);
-    pslot(P.ray_d, pid) = mkv4(r.d, u2f(st.z)); // the path's state word (dimension counter | flags | bounces) travels with the ray direction: a vertex
-                                         // that continues rewrites ray_d anyway, and `st` keeps only what never changes (Sobol' index, scramble)
-    pslot(P.beta, pid) = mkv4(splat3(1.0f), 1.0f);
+    pslot(P.ray_o[0], e) = mkv4(r.o, PT_INF);
+    pslot(P.ray_d[0], e) = mkv4(r.d, u2f(st.z)); // the path's state word (dimension counter | flags | bounces) travels with the ray direction: a vertex
+                                          // that continues rewrites ray_d anyway, and `st` keeps only what never changes (Sobol' index, scramble)
+    pslot(P.beta[0], e) = mkv4(splat3(1.0f), 1.0f);
     pslot(P.L, pid) = mkv4(splat3(0.0f), 0.0f);
     pslot(P.st, pid) = st;
     { f2a q; q.x = pf.x; q.y = pf.y; pslot(P.pfilm, pid) = q; }
@@ -83,7 +83,6 @@ PT_HD void generate_item(const DParams &R, const DSampler &S, const DCamera &C, 
 
 // t_max of every shadow ray: spawn_ray_to_it's 1 - 0.0001 (interaction.rs:50-60, Q13)
 #define PT_SHADOW_TMAX (1.0f - 0.0001f)
-struct alignas(8) PtU2 { uint32_t x, y; };
 
 PT_HD int32_t st_bounces(uint32_t z) { return (int32_t)(int16_t)(z >> ST_BOUNCE_SHIFT); }
 PT_HD uint32_t st_pack(uint32_t dim, uint32_t flags, int32_t bounces) { return (dim & ST_DIM_MASK) | flags | ((uint32_t)(uint16_t)(int16_t)bounces << ST_BOUNCE_SHIFT); }
@@ -93,8 +92,8 @@ PT_HD uint32_t st_pack(uint32_t dim, uint32_t flags, int32_t bounces) { return (
 // specular bounce, environment radiance for escaped rays, the depth cut -- then the material bucket.
 // Returns the bucket (0..5) when the path goes on to shading, -1 when it ends here.
 template <int FEAT>
-PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P, uint32_t pid, const HitRec &h) {
-    const v4 rdv = pslot(P.ray_d, pid);
+PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P, uint32_t par, uint32_t pid, uint32_t e, const HitRec &h) { // par: the round's parity; e: the path's position in the round's extension queue
+    const v4 rdv = pslot(P.ray_d[par], e);
     const uint32_t stz = f2u(rdv.w);
     const int32_t prim = h.prim;
     const int32_t bounces = st_bounces(stz);
@@ -106,13 +105,13 @@ PT_HD int extension_epilogue(const DParams &R, const DScene &sc, const DPaths &P
                 Surface s = tri_surface(T, prim, h.b0, h.b1, h.b2, -d);
                 f3 le = surface_le<FEAT>(sc, T, s, -d);
                 v4 Lv = pslot(P.L, pid);
-                f3 L = xyz(Lv) + xyz(pslot(P.beta, pid)) * le;
+                f3 L = xyz(Lv) + xyz(pslot(P.beta[par], e)) * le;
                 pslot(P.L, pid) = mkv4(L, Lv.w);
             }
         } else if ((FEAT & FEAT_INFINITE) && sc.n_inf > 0) {
             f3 d = xyz(rdv);
             v4 Lv = pslot(P.L, pid);
-            f3 L = xyz(Lv), beta = xyz(pslot(P.beta, pid));
+            f3 L = xyz(Lv), beta = xyz(pslot(P.beta[par], e));
             for (uint32_t i = 0; i < sc.n_inf; ++i) L = L + beta * light_le<FEAT>(sc, sc.lights[sc.inf_lights[i]], d);
             pslot(P.L, pid) = mkv4(L, Lv.w);
         }
@@ -204,17 +203,32 @@ struct ShadeCtx {
     PT_MEM void before_stores() const {}
 };
 
-struct ShadeResult { bool next; bool nee; bool shadow; bool mis; bool err_dim; PT_MEM uint32_t nee_entry(uint32_t pid) const { return pid | (shadow ? (uint32_t)NEE_Q_SHADOW : 0u) | (mis ? (uint32_t)NEE_Q_MIS : (uint32_t)NEE_Q_PRE); } }; // err_dim: a Sobol dimension >= 1024 was drawn (the reference panics, sobol.rs:177-183)
+// What a shading vertex leaves behind.  shade_item computes it and stores nothing: WHERE it goes is the caller's business -- the
+// continuing ray at the position the path gets in the next round's extension queue, the NEE record at the position of its entry in
+// the NEE queue (store_shade_out below, once the caller has handed out the positions).
+struct ShadeResult {
+    bool next; bool nee; bool shadow; bool mis; bool err_dim; // err_dim: a Sobol dimension >= 1024 was drawn (the reference panics, sobol.rs:177-183)
+    v4 ro, rd, beta;                     // next: the continuing ray (rd.w: the state word) and the throughput
+    v4 sh_o, sh_d, mis_o, mis_d, nee0, nee1; u4 nee2; float pre_z; // nee: the record (shadow: sh_*; mis: mis_*, nee0-2; neither mis: NEE_PRE, its contribution in sh_d.w, sh_o.w, pre_z)
+    PT_MEM uint32_t nee_entry(uint32_t pid) const { return pid | (shadow ? (uint32_t)NEE_Q_SHADOW : 0u) | (mis ? (uint32_t)NEE_Q_MIS : (uint32_t)NEE_Q_PRE); }
+};
+// e_next: the path's position in the next round's extension queue (used if r.next), f: the position of its NEE-queue entry (if r.nee)
+PT_HD void store_shade_out(const DPaths &P, uint32_t par_next, const ShadeResult &r, uint32_t e_next, uint32_t f) {
+    if (r.shadow) { pstore(P.sh_o, f, r.sh_o); pstore(P.sh_d, f, r.sh_d); }
+    if (r.mis) { pstore(P.mis_o, f, r.mis_o); pstore(P.mis_d, f, r.mis_d); pstore(P.nee0, f, r.nee0); pstore(P.nee1, f, r.nee1); pstore(P.nee2, f, r.nee2); } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1 / nee2)
+    else if (r.nee) pstore(P.pre_z, f, r.pre_z);
+    if (r.next) { pstore(P.ray_o[par_next], e_next, r.ro); pstore(P.ray_d[par_next], e_next, r.rd); pstore(P.beta[par_next], e_next, r.beta); }
+}
 
 // What a shading vertex reads of its path: five 16-byte vectors out of HBM (nothing else of a path is cache-resident: a
 // pass holds tens of GB of path state).  The gfx950 shade kernel fetches the NEXT item's PathIn while it shades the
 // current one (k_shade), which hides the one HBM round trip of the stage.
 struct PathIn { v4 ro, rd, beta; u4 st, hit; v4 pre0, pre1; }; // pre0 / pre1: the vertex's presampled environment-light sample (wi, pdf | Li, valid), where the context says so
-PT_HD PathIn load_path_in(const DPaths &P, uint32_t pid) { PathIn p; p.ro = pslot(P.ray_o, pid); p.rd = pslot(P.ray_d, pid); p.beta = pslot(P.beta, pid); p.st = pslot(P.st, pid); p.hit = pslot(P.hit, pid); p.pre0 = p.pre1 = mkv4(splat3(0.0f), 0.0f); return p; }
+PT_HD PathIn load_path_in(const DPaths &P, uint32_t par, uint32_t pid, uint32_t e) { PathIn p; p.ro = pslot(P.ray_o[par], e); p.rd = pslot(P.ray_d[par], e); p.beta = pslot(P.beta[par], e); p.st = pslot(P.st, pid); p.hit = pslot(P.hit, e); p.pre0 = p.pre1 = mkv4(splat3(0.0f), 0.0f); return p; }
 
 template <int MAT, int FEAT, class CTX = ShadeCtx>
 PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid, const PathIn &in, const CTX &X PT_STAMP_PARAMS) {
-    ShadeResult out; out.next = false; out.nee = false; out.shadow = false; out.mis = false; out.err_dim = false;
+    ShadeResult out; out.next = false; out.nee = false; out.shadow = false; out.mis = false; out.err_dim = false; out.pre_z = 0.0f;
     // ---- memory round trip 1: the path's state (already requested by the caller) ------------------------------------
     const v4 rov = in.ro, rdv = in.rd;
     v4 bv = in.beta;
@@ -255,10 +269,10 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
         CamRay cr = camera_ray(C, mk2(pf.x, pf.y), R.inv_sqrt_spp);
         surface_differentials(s, ro, cr.rx_d, ro, cr.ry_d);
     }
-    // Everything this vertex writes is collected in registers and stored at the very end, behind X.before_stores(): the
+    // Everything this vertex writes is collected in `out` and stored by the caller (store_shade_out), behind X.before_stores(): the
     // gfx950 kernel waits there for the NEXT item's prefetched state (vmcnt counts loads and stores alike, so waiting
     // anywhere after a store would also wait for that store).
-    v4 w_sh_o, w_sh_d, w_mis_o, w_mis_d, w_nee0, w_nee1, w_ro, w_rd, w_beta; u4 w_nee2; uint32_t w_stz = stv.z; float w_cz = 0.0f; bool w_pre = false;
+    v4 &w_sh_o = out.sh_o, &w_sh_d = out.sh_d, &w_mis_o = out.mis_o, &w_mis_d = out.mis_d, &w_nee0 = out.nee0, &w_nee1 = out.nee1, &w_ro = out.ro, &w_rd = out.rd, &w_beta = out.beta; u4 &w_nee2 = out.nee2; uint32_t w_stz = stv.z; float &w_cz = out.pre_z;
     bool w_skip = false; // null-BSDF skip: only the ray origin and the state word change
     w_sh_o = w_sh_d = w_mis_o = w_mis_d = w_nee0 = w_nee1 = w_ro = w_rd = w_beta = mkv4(splat3(0.0f), 0.0f); w_nee2.x = w_nee2.y = w_nee2.z = w_nee2.w = 0;
     BsdfT<MatLobes<MAT>::N> bsdf;
@@ -332,12 +346,11 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             if (!out.mis) { // shadow ray only (always, for delta lights): resolve_item's arithmetic with its one unknown, the occlusion, left open
                 f3 ld = splat3(0.0f);
                 ld = ld + A;
-                // (its three floats ride in free slots: sh_d.w, sh_o.w -- a shadow ray's t_max is the constant 1 - 1e-4, nobody reads it from
-                // there -- and ray_o.w, the slot of the extension ray's constant t_max, which a continuing vertex stores anyway; the record's kind
-                // travels in the queue entry (NEE_Q_PRE).  A shadow-only record is 32 bytes in two stores instead of 64 in four: the shade
-                // stage's time follows the bytes it writes.)
+                // (two of its three floats ride in free slots: sh_d.w, sh_o.w -- a shadow ray's t_max is the constant 1 - 1e-4, nobody reads it
+                // from there -- the third in pre_z; the record's kind travels in the queue entry (NEE_Q_PRE).  A shadow-only record is 36 bytes
+                // in three stores instead of 80 in five.)
                 const f3 c = beta * ((float)sc.n_lights * ld);
-                w_sh_d.w = c.x; w_sh_o.w = c.y; w_cz = c.z; w_pre = true;
+                w_sh_d.w = c.x; w_sh_o.w = c.y; w_cz = c.z;
             }
         }
     }
@@ -378,17 +391,9 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             out.next = true;
         }
     }
-    if (out.err_dim) { out.nee = false; out.shadow = false; out.mis = false; out.next = false; w_pre = false; }
+    if (out.err_dim) { out.nee = false; out.shadow = false; out.mis = false; out.next = false; }
     }
-    // ---- the vertex's stores ------------------------------------------------------------------------------------------
-    X.before_stores();
-    if (out.shadow) { pstore(P.sh_o, pid, w_sh_o); pstore(P.sh_d, pid, w_sh_d); }
-    if (out.mis) { pstore(P.mis_o, pid, w_mis_o); pstore(P.mis_d, pid, w_mis_d); }
-    if (out.mis) { pstore(P.nee0, pid, w_nee0); pstore(P.nee1, pid, w_nee1); pstore(P.nee2, pid, w_nee2); } // (a record without a MIS ray is NEE_PRE: nothing in nee0 / nee1 / nee2)
-    if (w_pre) { if (out.next) w_ro.w = w_cz; else reinterpret_cast<float *>(&pslot(P.ray_o, pid))[3] = w_cz; }
-    if (w_skip) { pstore(P.ray_o, pid, w_ro); pstore(P.ray_d, pid, mkv4(rd, u2f(w_stz))); out.next = true; }
-    else if (out.next) { pstore(P.ray_o, pid, w_ro); pstore(P.ray_d, pid, w_rd); pstore(P.beta, pid, w_beta); }
-    PT_STAMP(8, 0u)
+    if (w_skip) { w_rd = mkv4(rd, u2f(w_stz)); w_beta = bv; out.next = true; } // (the throughput moves with the ray: both are double-buffered by the round's parity)
     return out;
 }
 
@@ -398,20 +403,20 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
 // The part of estimate_direct after its two scene queries: `occluded` is the shadow ray's answer, `mh` the MIS ray's
 // closest hit (prim < 0: it escaped).
 template <int FEAT>
-PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, bool occluded, const HitRec &mh) {
+PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, uint32_t f, bool occluded, const HitRec &mh) { // f: the entry's position in the NEE queue, where its record is
     const uint32_t pid = entry & NEE_Q_PID;
-    if (entry & NEE_Q_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, sh_o.w, ray_o.w)
-        if (!occluded) { const f3 c = mk3(pslot(P.sh_d, pid).w, pslot(P.sh_o, pid).w, pslot(P.ray_o, pid).w); const v4 Lv = pslot(P.L, pid); pslot(P.L, pid) = mkv4(xyz(Lv) + c, Lv.w); }
+    if (entry & NEE_Q_PRE) { // the shade stage has done the arithmetic below for the unoccluded case (beta * nLights * ld in sh_d.w, sh_o.w, pre_z)
+        if (!occluded) { const f3 c = mk3(pslot(P.sh_d, f).w, pslot(P.sh_o, f).w, pslot(P.pre_z, f)); const v4 Lv = pslot(P.L, pid); pslot(P.L, pid) = mkv4(xyz(Lv) + c, Lv.w); }
         return;
     }
-    const u4 n2 = pslot(P.nee2, pid);
+    const u4 n2 = pslot(P.nee2, f);
     const uint32_t li = n2.w & 0xffffffu, fl = n2.w >> 24;
-    const v4 n0 = pslot(P.nee0, pid), n1 = pslot(P.nee1, pid);
+    const v4 n0 = pslot(P.nee0, f), n1 = pslot(P.nee1, f);
     f3 ld = splat3(0.0f);
     if ((fl & NEE_SHADOW) && !occluded) ld = ld + xyz(n0);
     if (fl & NEE_MIS) {
         const DLight &Lt = sc.lights[li];
-        const f3 wi = xyz(pslot(P.mis_d, pid));
+        const f3 wi = xyz(pslot(P.mis_d, f));
         f3 l2 = splat3(0.0f);
         if (mh.prim >= 0) {
             const TriRegs T = load_tri_regs(sc.shade + mh.prim);
@@ -429,33 +434,33 @@ PT_HD void resolve_item(const DScene &sc, const DPaths &P, uint32_t entry, bool 
 }
 
 template <int FEAT, bool QUAD, class Stack, class Geom>
-PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t entry, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
-    const uint32_t pid = entry & NEE_Q_PID;
+PT_HD void connect_item(const DScene &sc, const Geom &G, const DPaths &P, uint32_t entry, uint32_t f, Stack &stack, uint32_t &n_nodes, uint32_t &n_tris) {
     const uint32_t fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
     bool occluded = false;
     HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
     if (fl & NEE_SHADOW) {
-        const v4 o = pslot(P.sh_o, pid), d = pslot(P.sh_d, pid);
+        const v4 o = pslot(P.sh_o, f), d = pslot(P.sh_d, f);
         HitRec h;
         occluded = bvh_trace_g<QUAD, true, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(d), PT_SHADOW_TMAX, stack, h, n_nodes, n_tris); // (sh_o.w may hold a NEE_PRE record's payload)
     }
     if (fl & NEE_MIS) {
-        const v4 o = pslot(P.mis_o, pid);
-        if (!bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(pslot(P.mis_d, pid)), PT_INF, stack, mh, n_nodes, n_tris)) mh.prim = -1;
+        const v4 o = pslot(P.mis_o, f);
+        if (!bvh_trace_g<QUAD, false, (FEAT & FEAT_ALPHA) != 0>(G, sc, xyz(o), xyz(pslot(P.mis_d, f)), PT_INF, stack, mh, n_nodes, n_tris)) mh.prim = -1;
     }
-    resolve_item<FEAT>(sc, P, entry, occluded, mh);
+    resolve_item<FEAT>(sc, P, entry, f, occluded, mh);
 }
 
 // run-time material dispatch (host twin; the HIP back end launches one specialised kernel per bucket)
 template <int FEAT>
-PT_HD ShadeResult shade_dispatch(int bucket, const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t pid) {
+PT_HD ShadeResult shade_dispatch(int bucket, const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, uint32_t par, uint32_t pid, uint32_t e) {
+    const PathIn in = load_path_in(P, par, pid, e);
     switch (bucket) {
-        case 0: return shade_item<0, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
-        case 1: return shade_item<1, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
-        case 2: return shade_item<2, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
-        case 3: return shade_item<3, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
-        case 4: return shade_item<4, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
-        default: return shade_item<5, FEAT>(R, S, C, sc, P, pid, load_path_in(P, pid), ShadeCtx());
+        case 0: return shade_item<0, FEAT>(R, S, C, sc, P, pid, in, ShadeCtx());
+        case 1: return shade_item<1, FEAT>(R, S, C, sc, P, pid, in, ShadeCtx());
+        case 2: return shade_item<2, FEAT>(R, S, C, sc, P, pid, in, ShadeCtx());
+        case 3: return shade_item<3, FEAT>(R, S, C, sc, P, pid, in, ShadeCtx());
+        case 4: return shade_item<4, FEAT>(R, S, C, sc, P, pid, in, ShadeCtx());
+        default: return shade_item<5, FEAT>(R, S, C, sc, P, pid, in, ShadeCtx());
     }
 }
 

@@ -187,24 +187,37 @@ enum : uint32_t { ST_DIM_MASK = 0xfffu, ST_SPECULAR = 1u << 12, ST_HAS_DIFF = 1u
 enum : uint32_t { NEE_Q_PID = 0x07ffffffu, NEE_Q_SHADOW = 0x20000000u, NEE_Q_MIS = 0x40000000u, NEE_Q_PRE = 0x80000000u };
 // nee flags (stored in nee2.w as bits)
 enum : uint32_t { NEE_SHADOW = 1u, NEE_MIS = 2u,
-                  NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in (sh_d.w, sh_o.w, ray_o.w): the connect stage adds it when the ray is free
+                  NEE_PRE = 4u,          // shadow-only record whose contribution beta * nLights * ld is already in (sh_d.w, sh_o.w, pre_z): the connect stage adds it when the ray is free
                   NEE_OCCLUDED = 0x80u }; // set by the split connect stage when the shadow ray was blocked
 
+// Path state.  What a path carries from vertex to vertex travels IN QUEUE ORDER: the ray, its throughput and the hit sit at the
+// path's position `e` in the round's extension queue (e = segment * seg_cap + index: the index of the queue entry itself), the records of
+// a pending next-event estimation at the position `f` of its entry in the NEE queue.  The wave that owns a segment writes the
+// positions it hands out with wave_push -- consecutive ones: 64 lanes x 16 bytes are eight whole 128-byte lines -- and the stage
+// that consumes the queue reads them in order; round 2 indexed all of it by path slot, where the lanes of a wave touch as many
+// lines as paths (the slots of a segment's surviving paths drift apart as paths end).  What a path keeps for good stays at its slot
+// `pid`: the Sobol' index and scramble, the film position, the radiance.  The arrays written by one round's shade stage and read by
+// the next round's (ray, throughput) are double-buffered by the round's parity, like the extension queue.
+// (integrator.rs:399-405: l, beta, ray, bounces, specular_bounce, eta_scale)
 struct DPaths {
-    v4 *ray_o;  // o.xyz (an extension ray's t_max is +inf; nobody reads it from here); w: contribution .z of a pending NEE_PRE record
-    v4 *ray_d;  // d.xyz, the path's state word (dimension counter | flags | bounces): rewritten with the direction by every vertex that continues
-    v4 *beta;   // beta.rgb, eta_scale
-    v4 *L;      // L.rgb, (unused)
-    u4 *st;     // what never changes along a path: sobol index lo, hi (stratified: pixel, sample), (unused), pixel scramble -- written once by k_generate
-    u4 *hit;    // prim (int), b0, b1, b2 (float bits)
-    f2a *pfilm; // p_film.xy (8 bytes per path) -- written by generate, read by the film kernel
-    v4 *nee0;   // records with a MIS ray: A.rgb (light-sampling term, final if unoccluded), weight of the BSDF term
-    v4 *nee1;   // f.rgb of the BSDF term (already times |wi.ns|), scattering pdf
-    u4 *nee2;   // records with a MIS ray: beta at the vertex (rgb bits), light index | flags << 24
-    v4 *sh_o;   // shadow ray o.xyz (its t_max is the constant PT_SHADOW_TMAX); NEE_PRE records: contribution .y in w
-    v4 *sh_d;   // shadow ray d.xyz; NEE_PRE records: contribution .x in w
-    v4 *mis_o;  // MIS ray o.xyz
-    v4 *mis_d;  // MIS ray d.xyz
+    v4 *ray_o[2]; // [parity][e]: o.xyz, (t_max of an extension ray: +inf; nobody reads it from here)
+    v4 *ray_d[2]; // [parity][e]: d.xyz, the path's state word (dimension counter | flags | bounces): rewritten with the direction by every vertex that continues
+    v4 *beta[2];  // [parity][e]: beta.rgb, eta_scale
+    u4 *hit;      // [e]: prim (int), b0, b1, b2 (float bits) of the round's extension ray
+    v4 *pre0;     // [e]: environment-lit scenes, the vertex's presampled light sample (k_env_presample): wi.xyz, pdf
+    v4 *pre1;     // [e]: Li.rgb, valid
+    v4 *L;        // [pid]: L.rgb, 0
+    u4 *st;       // [pid]: what never changes along a path: sobol index lo, hi (stratified: pixel, sample), (unused), pixel scramble -- written once by k_generate
+    f2a *pfilm;   // [pid]: p_film.xy (8 bytes per path) -- written by generate, read by the film kernel
+    v4 *nee0;     // [f]: records with a MIS ray: A.rgb (light-sampling term, final if unoccluded), weight of the BSDF term
+    v4 *nee1;     // [f]: f.rgb of the BSDF term (already times |wi.ns|), scattering pdf
+    u4 *nee2;     // [f]: records with a MIS ray: beta at the vertex (rgb bits), light index | flags << 24
+    v4 *sh_o;     // [f]: shadow ray o.xyz (its t_max is the constant PT_SHADOW_TMAX); NEE_PRE records: contribution .y in w
+    v4 *sh_d;     // [f]: shadow ray d.xyz; NEE_PRE records: contribution .x in w
+    float *pre_z; // [f]: NEE_PRE records: contribution .z
+    v4 *mis_o;    // [f]: MIS ray o.xyz
+    v4 *mis_d;    // [f]: MIS ray d.xyz
+    u4 *nhit;     // [f]: the MIS ray's closest hit (connect stage -> resolve)
 };
 
 // queue counters: one row of uint32 per loop iteration
@@ -215,9 +228,10 @@ enum { CNT_EXT = 0, CNT_SHADOW = 1, CNT_MIS = 2, CNT_NODES = 3, CNT_TRIS = 4,
        CNT_STAMP0 = 16,                                            // diagnostic builds (-DPTRS_STAMPS): 12 phase clocks of k_shade
        CNT_NUM = 32 };
 
+struct alignas(8) MatEntry { uint32_t e, pid; }; // a shade-queue entry: the vertex's position in the round's extension queue (where its ray and hit are) and its path slot
 struct DQueues {
     uint32_t *ext[2];          // ping-pong extension-ray queues
-    uint32_t *mat[Q_NUM_MAT];  // one shade queue per material kind
+    MatEntry *mat[Q_NUM_MAT];  // one shade queue per material kind
     uint32_t *nee;             // paths with a pending next-event-estimation record this round
     uint32_t *counts;          // [iters][Q_STRIDE][G]
     uint32_t *tickets;         // [iters][Q_STRIDE][...]: segment tickets of the persistent queue kernels, one set of counters per launch of a pass

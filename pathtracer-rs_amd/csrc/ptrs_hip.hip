@@ -184,13 +184,14 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCame
     const uint32_t lane = threadIdx.x & 63u, s = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (s >= G) return;
     const uint32_t chunks = (R.n_paths + 63u) / 64u;
-    uint32_t *seg = Q.ext[0] + (size_t)s * seg_cap;
+    const uint32_t e0 = s * seg_cap; // the segment's first position in the queue-ordered arrays
     uint32_t n = 0;
     for (uint32_t c = s; c < chunks; c += G) {
         const uint32_t pid = c * 64u + lane;
         if (pid < R.n_paths) {
-            generate_item(R, S, C, P, pid);
-            seg[(c / G) * 64u + lane] = pid;
+            const uint32_t e = e0 + (c / G) * 64u + lane;
+            generate_item(R, S, C, P, pid, e);
+            pslot(Q.ext[0], e) = pid;
         }
         n += (c * 64u + 64u <= R.n_paths) ? 64u : (R.n_paths - c * 64u);
     }
@@ -445,16 +446,16 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
     uint32_t nn = 0, nt = 0; StepCount stepc;
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
-        const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)s * seg_cap;
+        const uint32_t e0 = s * seg_cap, par = it & 1u; // the segment's rays sit at positions e0 .. e0 + n of the round's ray arrays, in queue order: a refill is one coalesced read, no path slot is looked up
         const uint32_t n = rfl(*seg_count(Q, it, Q_EXT, Gn, s));
         uint32_t cursor = 0; // next entry of the segment: wave-uniform, a scalar register
         bool has = false;    // the lane holds an unfinished ray
-        uint32_t pid = 0;
+        uint32_t e = 0;      // its position
         RF_DECL LF_DECL // (per segment: nothing of a ray is live across the epilogue; quad-form kernels use the RF set, LDS-form kernels the LF set)
         for (;;) {
             if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this loop
                 u4 v; v.x = hit_pack(r_h.prim, r_h.flags); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-                pslot(P.hit, pid) = v;
+                pslot(P.hit, e) = v;
                 has = false;
             }
             const unsigned long long idle = __ballot(!has);
@@ -462,8 +463,8 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
             if (cursor < n && n_idle >= thresh) {
                 const uint32_t i = cursor + lanes_below(idle);
                 if (!has && i < n) {
-                    pid = pslot(queue, i);
-                    const v4 ov = pslot(P.ray_o, pid), dv = pslot(P.ray_d, pid);
+                    e = e0 + i;
+                    const v4 ov = pslot(P.ray_o[par], e), dv = pslot(P.ray_d[par], e);
                     if (GEOM > 0) LF_START(LG, xyz(ov), xyz(dv), PT_INF) else RF_START(xyz(ov), xyz(dv), PT_INF)
                     stk.clear(); has = true;
                 }
@@ -502,11 +503,11 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
     uint32_t nn = 0, nt = 0; StepCount stepc;
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
-        const uint32_t *__restrict__ queue = Q.nee + (size_t)s * seg_cap;
+        const uint32_t f0 = s * seg_cap; // the segment's records sit at positions f0 .. f0 + n of the NEE arrays, in the order of its queue entries
         const uint32_t n = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
         uint32_t cursor = 0;
         bool has = false, shadow_phase = false, setup = false;
-        uint32_t pid = 0, fl = 0;
+        uint32_t pid = 0, fl = 0, f = 0;
         f3 pre_l = splat3(0.0f); // NEE_PRE records: the path's radiance WITH the record's contribution (both fetched with the ray, added at once: three registers live across the traversal instead of seven), stored if the ray comes through
         RF_DECL LF_DECL // (per segment: nothing of a ray is live across the resolve)
         for (;;) {
@@ -516,12 +517,12 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
                         if (!r_hit) pslot(P.L, pid) = mkv4(pre_l, 0.0f); // (L.w is never anything but generate_item's 0)
                         has = false;
                     } else {
-                        if (r_hit) reinterpret_cast<uint32_t *>(&pslot(P.nee2, pid))[3] |= NEE_OCCLUDED << 24;
+                        if (r_hit) reinterpret_cast<uint32_t *>(&pslot(P.nee2, f))[3] |= NEE_OCCLUDED << 24;
                         if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
                     }
                 } else {
                     u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-                    pslot(P.hit, pid) = v;
+                    pslot(P.nhit, f) = v;
                     has = false;
                 }
             }
@@ -533,7 +534,8 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             if (batch && cursor < n && idle) {
                 const uint32_t i = cursor + lanes_below(idle);
                 if (!has && i < n) {
-                    const uint32_t entry = pslot(queue, i); // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
+                    f = f0 + i;
+                    const uint32_t entry = pslot(Q.nee, f); // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
                     pid = entry & NEE_Q_PID;
                     fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
                     if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
@@ -542,8 +544,8 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             }
             if (batch && setup) {
                 const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
-                const v4 o = pslot(po, pid), d = pslot(pd, pid);
-                if (shadow_phase && (fl & NEE_PRE)) { const f3 c = mk3(d.w, o.w, reinterpret_cast<const float *>(&pslot(P.ray_o, pid))[3]); pre_l = xyz(pslot(P.L, pid)) + c; } // shade_item's packing of a shadow-only record; resolve_item's sum
+                const v4 o = pslot(po, f), d = pslot(pd, f);
+                if (shadow_phase && (fl & NEE_PRE)) { const f3 c = mk3(d.w, o.w, pslot(P.pre_z, f)); pre_l = xyz(pslot(P.L, pid)) + c; } // shade_item's packing of a shadow-only record; resolve_item's sum
                 if (GEOM > 0) LF_START(LG, xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF) else RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
                 stk.clear(); setup = false;
             }
@@ -562,17 +564,17 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
 // estimate_direct's use of the two answers (integrator.rs:66-78, 121-134) and `l += beta * nLights * ld`, full waves
 template <int FEAT>
 __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t G, uint32_t s) {
-    const uint32_t *__restrict__ queue = Q.nee + (size_t)s * seg_cap;
+    const uint32_t f0 = s * seg_cap;
     const uint32_t n = rfl(*seg_count(Q, it, Q_NEE, G, s));
     if (rfl(*seg_count(Q, it, Q_MIS, G, s)) == 0) return; // every record of the segment was shadow-only: k_connect_rf has resolved them
     for (uint32_t i = __lane_id(); i < n; i += 64u) {
-        const uint32_t entry = pslot(queue, i);
+        const uint32_t f = f0 + i;
+        const uint32_t entry = pslot(Q.nee, f);
         if (entry & NEE_Q_PRE) continue; // shadow-only: resolved when its ray retired
-        const uint32_t pid = entry & NEE_Q_PID;
-        const uint32_t fl = pslot(P.nee2, pid).w >> 24;
+        const uint32_t fl = pslot(P.nee2, f).w >> 24;
         HitRec mh; mh.prim = -1; mh.t = 0.0f; mh.b0 = mh.b1 = mh.b2 = 0.0f; mh.flags = 0;
-        if (fl & NEE_MIS) { const u4 v = pslot(P.hit, pid); mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
-        resolve_item<FEAT>(sc, P, pid, (fl & NEE_OCCLUDED) != 0, mh);
+        if (fl & NEE_MIS) { const u4 v = pslot(P.nhit, f); mh.prim = (int32_t)v.x; mh.b0 = u2f(v.y); mh.b1 = u2f(v.z); mh.b2 = u2f(v.w); }
+        resolve_item<FEAT>(sc, P, entry, f, (fl & NEE_OCCLUDED) != 0, mh);
     }
 }
 template <int FEAT>
@@ -586,24 +588,24 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues 
 template <int FEAT>
 __device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t G, uint32_t s) {
     const uint32_t lane = __lane_id();
-    const uint32_t *__restrict__ queue = Q.ext[it & 1u] + (size_t)s * seg_cap;
+    const uint32_t e0 = s * seg_cap, par = it & 1u;
     const uint32_t n = rfl(*seg_count(Q, it, Q_EXT, G, s));
     uint32_t cnt[6] = {0u, 0u, 0u, 0u, 0u, 0u}; // wave-uniform: scalar registers
     for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-        const uint32_t i = i0 + lane;
+        const uint32_t i = i0 + lane, e = e0 + i;
         int k = -1; uint32_t pid = 0;
         if (i < n) {
-            pid = pslot(queue, i);
-            const u4 r = pslot(P.hit, pid);
+            pid = pslot(Q.ext[par], e);
+            const u4 r = pslot(P.hit, e); // (the hits, the state words and the path slots of 64 consecutive positions: three coalesced reads)
             HitRec h; h.prim = hit_prim(r.x); h.t = 0.0f; h.b0 = u2f(r.y); h.b1 = u2f(r.z); h.b2 = u2f(r.w);
             h.flags = hit_flags(r.x); // the two fields of the leaf record's flags the epilogue reads
-            k = extension_epilogue<FEAT>(R, sc, P, pid, h);
+            k = extension_epilogue<FEAT>(R, sc, P, par, pid, e, h);
         }
 #pragma unroll
         for (int m = 0; m < 6; ++m) { // wavefront-ballot bucketing by material kind
             if (!(kinds_mask & (1u << m))) continue;
             const uint32_t slot = wave_push(cnt[m], k == m);
-            if (k == m) pslot(Q.mat[m] + (size_t)s * seg_cap, slot) = pid;
+            if (k == m) { MatEntry me; me.e = e; me.pid = pid; pslot(Q.mat[m], e0 + slot) = me; }
         }
     }
     if (lane == 0) {
@@ -752,31 +754,31 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
     // no registers held while they fly) before it shades the current item, and shade_item waits for them right before it issues
     // its stores (before_stores) -- by then they have had a whole vertex's time to arrive.  The queue entry is read two items
     // ahead.  Vector k of wave w sits at lds_pf[(k * 4 + w) * 64 + lane].
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    auto dma = [&](uint32_t p) {
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, par = it & 1u;
+    auto dma = [&](const MatEntry &m) { // the vertex's ray, throughput and hit at its position in the round's extension queue, the path's constants at its slot
         typedef __attribute__((address_space(1))) const void gptr; typedef __attribute__((address_space(3))) void lptr;
-        if (FEAT & FEAT_IMAGE) __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.ray_o, p), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0); // (the ray's origin is only read for the camera ray's differentials, which only image-texture lookups use)
-        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.ray_d, p), (lptr *)(lds_pf + (1u * 4u + wv) * 64u), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.beta, p), (lptr *)(lds_pf + (2u * 4u + wv) * 64u), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.st, p), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.hit, p), (lptr *)(lds_pf + (4u * 4u + wv) * 64u), 16, 0, 0);
+        if (FEAT & FEAT_IMAGE) __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.ray_o[par], m.e), (lptr *)(lds_pf + (0u * 4u + wv) * 64u), 16, 0, 0); // (the ray's origin is only read for the camera ray's differentials, which only image-texture lookups use)
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.ray_d[par], m.e), (lptr *)(lds_pf + (1u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.beta[par], m.e), (lptr *)(lds_pf + (2u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.st, m.pid), (lptr *)(lds_pf + (3u * 4u + wv) * 64u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.hit, m.e), (lptr *)(lds_pf + (4u * 4u + wv) * 64u), 16, 0, 0);
         if ((FEAT & FEAT_INFINITE) && cfg.pre_li != 0xffffffffu) {
-            __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.nee0, p), (lptr *)(lds_pf + (5u * 4u + wv) * 64u), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.nee1, p), (lptr *)(lds_pf + (6u * 4u + wv) * 64u), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.pre0, m.e), (lptr *)(lds_pf + (5u * 4u + wv) * 64u), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.pre1, m.e), (lptr *)(lds_pf + (6u * 4u + wv) * 64u), 16, 0, 0);
         }
     };
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
-        const uint32_t *__restrict__ queue = Q.mat[MAT] + (size_t)s * seg_cap;
+        const MatEntry *__restrict__ queue = Q.mat[MAT] + (size_t)s * seg_cap;
         const uint32_t n = rfl(*seg_count(Q, it, Q_MAT0 + MAT, Gn, s));
         if (n == 0) continue;
         // several material kernels append to the same output segments one after the other
         const uint32_t next_base = rfl(*seg_count(Q, it + 1u, Q_EXT, Gn, s)), nee_base = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
-        uint32_t *next = Q.ext[(it + 1u) & 1u] + (size_t)s * seg_cap + next_base;
-        uint32_t *nee = Q.nee + (size_t)s * seg_cap + nee_base;
+        const uint32_t e_next0 = s * seg_cap + next_base, f0 = s * seg_cap + nee_base; // where this launch's first continuing ray / first NEE record goes
         uint32_t c_next = 0, c_nee = 0, c_shadow = 0, c_mis = 0; // the segment's output counters: wave-uniform, scalar registers
-        uint32_t i = lane, pid = 0, pid1 = 0;
-        if (i < n) { pid = pslot(queue, i); dma(pid); }
-        if (i + 64u < n) pid1 = pslot(queue, i + 64u);
+        uint32_t i = lane;
+        MatEntry m, m1; m.e = m.pid = m1.e = m1.pid = 0;
+        if (i < n) { m = pslot(queue, i); dma(m); }
+        if (i + 64u < n) m1 = pslot(queue, i + 64u);
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first item's state is in LDS
         while (i < n) {
             PathIn in;
@@ -791,23 +793,28 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
             }
             __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS reads are done before the next DMA overwrites the buffer
             const uint32_t i2 = i + 64u;
-            if (i2 < n) dma(pid1);
-            uint32_t pid2 = 0;
-            if (i2 + 64u < n) pid2 = pslot(queue, i2 + 64u);
+            if (i2 < n) dma(m1);
+            MatEntry m2; m2.e = m2.pid = 0;
+            if (i2 + 64u < n) m2 = pslot(queue, i2 + 64u);
 #ifdef PTRS_STAMPS
-            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X, stamp_acc, stamp_last);
-            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[9] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; } // early returns land here
+            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, m.pid, in, X, stamp_acc, stamp_last);
 #else
-            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, pid, in, X);
+            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, m.pid, in, X);
 #endif
             err_dim = err_dim || r.err_dim;
-            uint32_t slot = wave_push(c_next, r.next);
-            if (r.next) pslot(next, slot) = pid;
-            slot = wave_push(c_nee, r.nee);
-            if (r.nee) pslot(nee, slot) = r.nee_entry(pid);
+            // the vertex's stores: the continuing ray at the position the path takes in the next round's extension queue, the NEE record at
+            // the position of its queue entry -- consecutive positions for the lanes of the wave, whole 128-byte lines
+            const uint32_t e_next = e_next0 + wave_push(c_next, r.next), f = f0 + wave_push(c_nee, r.nee);
+            X.before_stores();
+            store_shade_out(P, par ^ 1u, r, e_next, f);
+            if (r.next) pslot(Q.ext[par ^ 1u], e_next) = m.pid;
+            if (r.nee) pslot(Q.nee, f) = r.nee_entry(m.pid);
+#ifdef PTRS_STAMPS
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[8] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; }
+#endif
             c_shadow += (uint32_t)__popcll(__ballot(r.shadow));
             c_mis += (uint32_t)__popcll(__ballot(r.mis));
-            i = i2; pid = pid1; pid1 = pid2;
+            i = i2; m = m1; m1 = m2;
         }
         if (lane == 0) { // the wave is the segment's only writer in this launch
             *seg_count(Q, it + 1u, Q_EXT, Gn, s) = next_base + c_next;
@@ -851,12 +858,12 @@ __global__ __launch_bounds__(BLOCK) void k_env_presample(DSampler S, DScene sc, 
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
         for (int m = 0; m < 6; ++m) {
             if (!(nee_kinds & (1u << m))) continue;
-            const uint32_t *__restrict__ queue = Q.mat[m] + (size_t)s * seg_cap;
+            const MatEntry *__restrict__ queue = Q.mat[m] + (size_t)s * seg_cap;
             const uint32_t n = rfl(*seg_count(Q, it, Q_MAT0 + m, Gn, s));
             for (uint32_t i = lane; i < n; i += 64u) {
-                const uint32_t pid = pslot(queue, i);
-                const u4 stv = pslot(P.st, pid);
-                const uint32_t field = f2u(pslot(P.ray_d, pid).w) & ST_DIM_MASK;
+                const MatEntry me = pslot(queue, i);
+                const u4 stv = pslot(P.st, me.pid);
+                const uint32_t field = f2u(pslot(P.ray_d[it & 1u], me.e).w) & ST_DIM_MASK;
                 const VertexDims V = vertex_dims(field, true);
                 const uint64_t index = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
                 const uint32_t dc[1] = {V.nee[4]};
@@ -871,8 +878,8 @@ __global__ __launch_bounds__(BLOCK) void k_env_presample(DSampler S, DScene sc, 
                 X.sobol<2>(S, index, dn, stv.w, u);
                 f3 wi, rgb; float pdf;
                 const bool ok = inf_light_sample(sc, Le, mk2(u[0], u[1]), wi, pdf, rgb, &marg);
-                pslot(P.nee0, pid) = mkv4(wi, pdf);
-                pslot(P.nee1, pid) = mkv4(rgb, u2f(ok ? 1u : 0u));
+                pslot(P.pre0, me.e) = mkv4(wi, pdf);
+                pslot(P.pre1, me.e) = mkv4(rgb, u2f(ok ? 1u : 0u));
             }
         }
     }
@@ -948,7 +955,7 @@ __global__ __launch_bounds__(64) void k_strat_tables(int32_t NX, int32_t NY, uin
 __global__ __launch_bounds__(BLOCK) void k_dump_rays(DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t G, uint32_t max_rays, float *out, uint32_t *n_out) {
     const uint32_t lane = threadIdx.x & 63u, s = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (s >= G) return;
-    const uint32_t *queue = Q.ext[it & 1u] + (size_t)s * seg_cap;
+    const uint32_t e0 = s * seg_cap, par = it & 1u;
     const uint32_t n = *seg_count(Q, it, Q_EXT, G, s);
     for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
         const uint32_t i = i0 + lane, cnt = n - i0 < 64u ? n - i0 : 64u;
@@ -956,8 +963,7 @@ __global__ __launch_bounds__(BLOCK) void k_dump_rays(DPaths P, DQueues Q, uint32
         if (lane == 0) base = atomicAdd(n_out, cnt);
         base = rfl(base);
         if (i < n && base + lane < max_rays) {
-            const uint32_t pid = queue[i];
-            const v4 o = pslot(P.ray_o, pid), d = pslot(P.ray_d, pid);
+            const v4 o = pslot(P.ray_o[par], e0 + i), d = pslot(P.ray_d[par], e0 + i);
             float *r = out + (size_t)(base + lane) * 7u;
             r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = PT_INF;
         }
@@ -1120,7 +1126,7 @@ struct HipBackend {
         lane_[cur] = Lane{stream, R, P, Q, G, seg_cap};
         cur = l; stream = lane_[l].stream; R = lane_[l].R; P = lane_[l].P; Q = lane_[l].Q; G = lane_[l].G; seg_cap = lane_[l].seg_cap;
     }
-    // paths per pass and lane that keep the whole workspace (14 state vectors + 3 + kinds queues per path, all lanes) inside
+    // paths per pass and lane that keep the whole workspace (17-19 state vectors + the queues per path, all lanes) inside
     // opt.workspace_pct of the memory that is free now plus what this scene already holds from earlier renders
     uint64_t auto_capacity(uint32_t lanes_n, const bool *kinds) {
         size_t fr = 0, tot = 0;
@@ -1128,7 +1134,7 @@ struct HipBackend {
         size_t held = 0;
         for (auto &l : ps->ws) for (auto &b : l) held += b.bytes;
         uint32_t nk = 0; for (int k = 0; k < 7; ++k) nk += kinds[k] ? 1u : 0u;
-        const double per_path = 13.0 * 16.0 + 8.0 + (3.0 + nk) * 4.0; // 13 state vectors, the 8-byte film position, the queues
+        const double per_path = (17.0 + (ps->H.inf_lights.empty() ? 0.0 : 2.0)) * 16.0 + 8.0 + 4.0 + 3.0 * 4.0 + nk * 8.0; // 15 vectors in queue order (ray, throughput double-buffered), 2 by path slot, the presampled light sample, the film position, pre_z, three queues, the shade queues
         const double budget = (double)(fr + held) * (double)opt.workspace_pct / 100.0 / (double)std::max(1, share); // `share` renders divide this device's memory (ptrs_render_multi)
         const double cap = budget / (per_path * (double)lanes_n);
         return cap < 65536.0 ? 65536ull : (uint64_t)cap;
@@ -1228,20 +1234,31 @@ struct HipBackend {
             if (l > 0 && !ps->lane_stream[l] && hipStreamCreateWithFlags(&ps->lane_stream[l], hipStreamNonBlocking) != hipSuccess) { err = "cannot create a pipeline stream"; return PTRS_ERR_DEVICE; }
             if (!ps->lane_ev[l] && hipEventCreateWithFlags(&ps->lane_ev[l], hipEventDisableTiming) != hipSuccess) { err = "cannot create pipeline events"; return PTRS_ERR_DEVICE; }
         }
+        const size_t nq = n4 / 4; // positions of a queue, and of every array in queue order
+        const bool presampled = presample_li() != 0xffffffffu;
         for (uint32_t l = 0; l < n_lanes; ++l) {
             DPaths Pl; DQueues Ql;
-            void **slots16[] = {(void **)&Pl.ray_o, (void **)&Pl.ray_d, (void **)&Pl.beta, (void **)&Pl.L, (void **)&Pl.st, (void **)&Pl.hit, (void **)&Pl.nee0,
-                                (void **)&Pl.nee1, (void **)&Pl.nee2, (void **)&Pl.sh_o, (void **)&Pl.sh_d, (void **)&Pl.mis_o, (void **)&Pl.mis_d};
+            std::memset(&Pl, 0, sizeof(Pl));
             int w = 0;
-            for (auto sl : slots16) { if ((rc = ps->ws[l][w].ensure(n16)) != PTRS_OK) { err = g_err + " (path state of pipeline lane " + std::to_string(l) + "; ptrs_set_option(\"lanes\", 1) or a smaller workspace_pct shrink the workspace)"; return rc; } *sl = ps->ws[l][w++].p; }
-            if ((rc = ps->ws[l][w].ensure((size_t)cap * 8)) != PTRS_OK) { err = g_err; return rc; }
-            Pl.pfilm = (f2a *)ps->ws[l][w++].p;
+            auto take = [&](size_t bytes, void **out, const char *what) -> int {
+                int r = ps->ws[l][w].ensure(bytes);
+                if (r != PTRS_OK) { err = g_err + " (" + what + " of pipeline lane " + std::to_string(l) + "; ptrs_set_option(\"lanes\", 1) or a smaller workspace_pct shrink the workspace)"; return r; }
+                *out = ps->ws[l][w++].p;
+                return PTRS_OK;
+            };
+            void **by_queue16[] = {(void **)&Pl.ray_o[0], (void **)&Pl.ray_o[1], (void **)&Pl.ray_d[0], (void **)&Pl.ray_d[1], (void **)&Pl.beta[0], (void **)&Pl.beta[1], (void **)&Pl.hit,
+                                   (void **)&Pl.nee0, (void **)&Pl.nee1, (void **)&Pl.nee2, (void **)&Pl.sh_o, (void **)&Pl.sh_d, (void **)&Pl.mis_o, (void **)&Pl.mis_d, (void **)&Pl.nhit};
+            for (auto sl : by_queue16) if ((rc = take(nq * 16, sl, "path state")) != PTRS_OK) return rc;
+            void **by_slot16[] = {(void **)&Pl.L, (void **)&Pl.st};
+            for (auto sl : by_slot16) if ((rc = take(n16, sl, "path state")) != PTRS_OK) return rc;
+            if ((rc = take((size_t)cap * 8, (void **)&Pl.pfilm, "path state")) != PTRS_OK) return rc;
+            if ((rc = take(nq * 4, (void **)&Pl.pre_z, "path state")) != PTRS_OK) return rc;
+            if (presampled) { if ((rc = take(nq * 16, (void **)&Pl.pre0, "path state")) != PTRS_OK || (rc = take(nq * 16, (void **)&Pl.pre1, "path state")) != PTRS_OK) return rc; } else w += 2;
             void **slots4[] = {(void **)&Ql.ext[0], (void **)&Ql.ext[1], (void **)&Ql.nee};
-            for (auto sl : slots4) { if ((rc = ps->ws[l][w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } *sl = ps->ws[l][w++].p; }
+            for (auto sl : slots4) if ((rc = take(n4, sl, "queues")) != PTRS_OK) return rc;
             for (int k = 0; k < Q_NUM_MAT; ++k) {
                 Ql.mat[k] = nullptr;
-                if (kinds_mask & (1u << k)) { if ((rc = ps->ws[l][w].ensure(n4)) != PTRS_OK) { err = g_err; return rc; } Ql.mat[k] = (uint32_t *)ps->ws[l][w].p; }
-                ++w;
+                if (kinds_mask & (1u << k)) { if ((rc = take(nq * sizeof(MatEntry), (void **)&Ql.mat[k], "queues")) != PTRS_OK) return rc; } else ++w;
             }
             if ((rc = ps->counts[l].ensure((size_t)rows * Q_STRIDE * (size_t)grid_max * 4)) != PTRS_OK || (rc = ps->totals[l].ensure((size_t)rows * Q_STRIDE * 4)) != PTRS_OK ||
                 (rc = ps->tickets[l].ensure(((size_t)rows * Q_STRIDE * TK_LAUNCH_WORDS + rows) * 4)) != PTRS_OK) { err = g_err; return rc; }
@@ -1819,22 +1836,27 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
         const uint32_t chunks = (n + 63u) / 64u, gmax = (uint32_t)scene->n_cu * 8u * (uint32_t)(be.opt.grid_mult ? be.opt.grid_mult : 8); // (one launch at a time: the single-lane segmentation)
         const uint32_t G = chunks < gmax ? chunks : gmax, seg_cap = ((chunks + G - 1) / G) * 64u;
         be.G = G; be.seg_cap = seg_cap;
-        std::vector<v4> ro(n), rd(n);
-        for (uint32_t i = 0; i < n; ++i) { ro[i].x = rays[7 * i]; ro[i].y = rays[7 * i + 1]; ro[i].z = rays[7 * i + 2]; ro[i].w = rays[7 * i + 6]; rd[i].x = rays[7 * i + 3]; rd[i].y = rays[7 * i + 4]; rd[i].z = rays[7 * i + 5]; rd[i].w = 0.0f; }
-        std::vector<uint32_t> q((size_t)G * seg_cap, 0u), cnt((size_t)Q_STRIDE * G, 0u);
+        // the rays in queue order, as a frame's shade stage leaves them: ray i = 64 c + k sits at position (c mod G) seg_cap + (c / G) 64 + k
+        const size_t nq = (size_t)G * seg_cap;
+        std::vector<v4> ro(nq), rd(nq);
+        std::vector<uint32_t> q(nq, 0u), cnt((size_t)Q_STRIDE * G, 0u);
         for (uint32_t c = 0; c < chunks; ++c) {
             const uint32_t s = c % G, m = c * 64u + 64u <= n ? 64u : n - c * 64u;
-            for (uint32_t k = 0; k < m; ++k) q[(size_t)s * seg_cap + (c / G) * 64u + k] = c * 64u + k;
+            for (uint32_t k = 0; k < m; ++k) {
+                const uint32_t i = c * 64u + k; const size_t e = (size_t)s * seg_cap + (c / G) * 64u + k;
+                q[e] = i;
+                ro[e].x = rays[7 * i]; ro[e].y = rays[7 * i + 1]; ro[e].z = rays[7 * i + 2]; ro[e].w = rays[7 * i + 6]; rd[e].x = rays[7 * i + 3]; rd[e].y = rays[7 * i + 4]; rd[e].z = rays[7 * i + 5]; rd[e].w = 0.0f;
+            }
             cnt[(size_t)Q_EXT * G + s] += m;
         }
         DevBuf bo, bd, bh, bq, bc, bt, bs;
         auto cleanup = [&]() { bo.release(); bd.release(); bh.release(); bq.release(); bc.release(); bt.release(); bs.release(); };
         int rc;
         const size_t tk_words = (size_t)(repeats + 1) * TK_LAUNCH_WORDS + 4;
-        if ((rc = upload(bo, ro)) || (rc = upload(bd, rd)) || (rc = bh.ensure((size_t)n * 16)) || (rc = upload(bq, q)) || (rc = upload(bc, cnt)) || (rc = bt.ensure(tk_words * 4)) || (rc = bs.ensure(CNT_NUM * 8))) { cleanup(); return rc; }
+        if ((rc = upload(bo, ro)) || (rc = upload(bd, rd)) || (rc = bh.ensure(nq * 16)) || (rc = upload(bq, q)) || (rc = upload(bc, cnt)) || (rc = bt.ensure(tk_words * 4)) || (rc = bs.ensure(CNT_NUM * 8))) { cleanup(); return rc; }
         hipError_t e = hipMemset(bt.p, 0, tk_words * 4);
         if (e == hipSuccess) e = hipMemset(bs.p, 0, CNT_NUM * 8);
-        DPaths P; std::memset(&P, 0, sizeof(P)); P.ray_o = (v4 *)bo.p; P.ray_d = (v4 *)bd.p; P.hit = (u4 *)bh.p;
+        DPaths P; std::memset(&P, 0, sizeof(P)); P.ray_o[0] = (v4 *)bo.p; P.ray_d[0] = (v4 *)bd.p; P.hit = (u4 *)bh.p;
         DQueues Q; std::memset(&Q, 0, sizeof(Q)); Q.ext[0] = (uint32_t *)bq.p; Q.counts = (uint32_t *)bc.p; Q.stats = (unsigned long long *)bs.p; Q.tickets = (uint32_t *)bt.p; Q.alive = (uint32_t *)bt.p + (size_t)(repeats + 1) * TK_LAUNCH_WORDS;
         DParams R; std::memset(&R, 0, sizeof(R)); R.n_paths = n;
         StackSpill sp = scene->spill;
@@ -1859,9 +1881,15 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
             stats->nodes_visited = hs[CNT_NODES]; stats->tris_tested = hs[CNT_TRIS];
         }
         if (e == hipSuccess && hits_out) {
-            std::vector<u4> hh(n);
-            e = hipMemcpy(hh.data(), bh.p, (size_t)n * 16, hipMemcpyDeviceToHost);
-            for (uint32_t i = 0; i < n; ++i) { hits_out[i].prim = hit_prim(hh[i].x); hits_out[i].b0 = u2f(hh[i].y); hits_out[i].b1 = u2f(hh[i].z); hits_out[i].b2 = u2f(hh[i].w); hits_out[i].t = 0.0f; }
+            std::vector<u4> hh(nq);
+            e = hipMemcpy(hh.data(), bh.p, nq * 16, hipMemcpyDeviceToHost);
+            for (uint32_t c = 0; c < chunks; ++c) {
+                const uint32_t s = c % G, m = c * 64u + 64u <= n ? 64u : n - c * 64u;
+                for (uint32_t k = 0; k < m; ++k) {
+                    const uint32_t i = c * 64u + k; const u4 h = hh[(size_t)s * seg_cap + (c / G) * 64u + k];
+                    hits_out[i].prim = hit_prim(h.x); hits_out[i].b0 = u2f(h.y); hits_out[i].b1 = u2f(h.z); hits_out[i].b2 = u2f(h.w); hits_out[i].t = 0.0f;
+                }
+            }
         }
         stats->ms_trace = ms; stats->ms_extend = ms; stats->trace_launches = repeats; stats->extend_launches = repeats; stats->kernel_launches = repeats + 1; stats->rays_extension = (uint64_t)n * repeats;
         stats->queue_segments = G; stats->grid_wgs[0] = grid; stats->resident_wgs_per_cu[0] = be.last_per_cu[HipBackend::T_EXTEND];

@@ -70,11 +70,13 @@ struct HostBackend {
         (void)bvh_depth;
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; feat = g_force_full ? FEAT_FULL : feat_;
         gaussian_filter_table(table);
-        P.ray_o = alloc<v4>(cap); P.ray_d = alloc<v4>(cap); P.beta = alloc<v4>(cap); P.L = alloc<v4>(cap); P.st = alloc<u4>(cap); P.hit = alloc<u4>(cap);
+        // (one queue segment: a path's position in a queue is the index of its entry)
+        for (int b = 0; b < 2; ++b) { P.ray_o[b] = alloc<v4>(cap); P.ray_d[b] = alloc<v4>(cap); P.beta[b] = alloc<v4>(cap); }
+        P.L = alloc<v4>(cap); P.st = alloc<u4>(cap); P.hit = alloc<u4>(cap); P.pre0 = P.pre1 = nullptr;
         P.pfilm = alloc<f2a>(cap); P.nee0 = alloc<v4>(cap); P.nee1 = alloc<v4>(cap); P.nee2 = alloc<u4>(cap); P.sh_o = alloc<v4>(cap); P.sh_d = alloc<v4>(cap);
-        P.mis_o = alloc<v4>(cap); P.mis_d = alloc<v4>(cap);
+        P.mis_o = alloc<v4>(cap); P.mis_d = alloc<v4>(cap); P.nhit = alloc<u4>(cap); P.pre_z = alloc<float>(cap);
         Q.ext[0] = alloc<uint32_t>(cap); Q.ext[1] = alloc<uint32_t>(cap);
-        for (int k = 0; k < Q_NUM_MAT; ++k) Q.mat[k] = alloc<uint32_t>(cap);
+        for (int k = 0; k < Q_NUM_MAT; ++k) Q.mat[k] = alloc<MatEntry>(cap);
         Q.nee = alloc<uint32_t>(cap);
         Q.counts = alloc<uint32_t>((size_t)rows * Q_STRIDE); Q.stats = alloc<unsigned long long>(CNT_NUM);
         return PTRS_OK;
@@ -85,31 +87,33 @@ struct HostBackend {
     void pass_begin(const DParams &R_) { R = R_; std::memset(Q.counts, 0, (size_t)rows * Q_STRIDE * 4); }
     uint32_t &cnt(uint32_t it, int q) { return Q.counts[(size_t)it * Q_STRIDE + q]; }
     void generate() {
-        for (uint32_t pid = 0; pid < R.n_paths; ++pid) { generate_item(R, S, C, P, pid); Q.ext[0][pid] = pid; }
+        for (uint32_t pid = 0; pid < R.n_paths; ++pid) { generate_item(R, S, C, P, pid, pid); Q.ext[0][pid] = pid; }
         cnt(0, Q_EXT) = R.n_paths;
     }
     template <int FEAT> void extend_t(uint32_t it) {
-        const uint32_t *q = Q.ext[it & 1];
+        const uint32_t *q = Q.ext[it & 1], par = it & 1u;
         for (uint32_t i = 0, n = cnt(it, Q_EXT); i < n; ++i) {
             const uint32_t pid = q[i];
-            const v4 o = P.ray_o[pid], d = P.ray_d[pid];
+            const v4 o = P.ray_o[par][i], d = P.ray_d[par][i];
             CheckedStack stk = make_stack(); HitRec h; uint32_t nn = 0, nt = 0;
             bvh_trace_any_form<false, (FEAT & FEAT_ALPHA) != 0>(sc, xyz(o), xyz(d), PT_INF, stk, h, nn, nt);
             nodes += nn; tris += nt;
-            u4 r; r.x = hit_pack(h.prim, h.flags); r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[pid] = r;
-            const int k = extension_epilogue<FEAT>(R, sc, P, pid, h);
-            if (k >= 0) Q.mat[k][cnt(it, Q_MAT0 + k)++] = pid;
+            u4 r; r.x = hit_pack(h.prim, h.flags); r.y = f2u(h.b0); r.z = f2u(h.b1); r.w = f2u(h.b2); P.hit[i] = r;
+            const int k = extension_epilogue<FEAT>(R, sc, P, par, pid, i, h);
+            if (k >= 0) { MatEntry me; me.e = i; me.pid = pid; Q.mat[k][cnt(it, Q_MAT0 + k)++] = me; }
         }
     }
     void extend(uint32_t it) { if (feat_trace != FEAT_SIMPLE) extend_t<FEAT_FULL>(it); else extend_t<FEAT_SIMPLE>(it); } // (FEAT_IMG_ENV: the full set gives the same results)
     void shade(uint32_t it, int kind) {
-        const uint32_t *q = Q.mat[kind];
+        const MatEntry *q = Q.mat[kind];
         uint32_t *next = Q.ext[(it + 1) & 1];
+        const uint32_t par = it & 1u;
         for (uint32_t i = 0, n = cnt(it, Q_MAT0 + kind); i < n; ++i) {
-            const uint32_t pid = q[i];
-            const ShadeResult r = feat == FEAT_SIMPLE ? shade_dispatch<FEAT_SIMPLE>(kind, R, S, C, sc, P, pid) : feat == FEAT_IMG ? shade_dispatch<FEAT_IMG>(kind, R, S, C, sc, P, pid)
-                                : feat == FEAT_IMG_ENV ? shade_dispatch<FEAT_IMG_ENV>(kind, R, S, C, sc, P, pid) : shade_dispatch<FEAT_FULL>(kind, R, S, C, sc, P, pid);
+            const uint32_t pid = q[i].pid, e = q[i].e;
+            const ShadeResult r = feat == FEAT_SIMPLE ? shade_dispatch<FEAT_SIMPLE>(kind, R, S, C, sc, P, par, pid, e) : feat == FEAT_IMG ? shade_dispatch<FEAT_IMG>(kind, R, S, C, sc, P, par, pid, e)
+                                : feat == FEAT_IMG_ENV ? shade_dispatch<FEAT_IMG_ENV>(kind, R, S, C, sc, P, par, pid, e) : shade_dispatch<FEAT_FULL>(kind, R, S, C, sc, P, par, pid, e);
             err_dim = err_dim || r.err_dim;
+            store_shade_out(P, par ^ 1u, r, cnt(it + 1, Q_EXT), cnt(it, Q_NEE)); // (the positions the two pushes below hand out)
             if (r.next) next[cnt(it + 1, Q_EXT)++] = pid;
             if (r.shadow) cnt(it, Q_SHADOW)++;
             if (r.mis) cnt(it, Q_MIS)++;
@@ -120,8 +124,8 @@ struct HostBackend {
         for (uint32_t i = 0, n = cnt(it, Q_NEE); i < n; ++i) {
             CheckedStack stk = make_stack(); uint32_t nn = 0, nt = 0;
             const GeomGlobal G = geom_global(sc);
-            if (sc.n_nodes4) { if (feat_trace != FEAT_SIMPLE) connect_item<FEAT_FULL, true>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, true>(sc, G, P, Q.nee[i], stk, nn, nt); }
-            else { if (feat_trace != FEAT_SIMPLE) connect_item<FEAT_FULL, false>(sc, G, P, Q.nee[i], stk, nn, nt); else connect_item<FEAT_SIMPLE, false>(sc, G, P, Q.nee[i], stk, nn, nt); }
+            if (sc.n_nodes4) { if (feat_trace != FEAT_SIMPLE) connect_item<FEAT_FULL, true>(sc, G, P, Q.nee[i], i, stk, nn, nt); else connect_item<FEAT_SIMPLE, true>(sc, G, P, Q.nee[i], i, stk, nn, nt); }
+            else { if (feat_trace != FEAT_SIMPLE) connect_item<FEAT_FULL, false>(sc, G, P, Q.nee[i], i, stk, nn, nt); else connect_item<FEAT_SIMPLE, false>(sc, G, P, Q.nee[i], i, stk, nn, nt); }
             nodes += nn; tris += nt;
         }
     }
