@@ -538,6 +538,11 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
                     const uint32_t entry = pslot(Q.nee, f); // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
                     pid = entry & NEE_Q_PID;
                     fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
+#if defined(PTRS_ABL_CONNECT_ONLY) && PTRS_ABL_CONNECT_ONLY == 1
+                    fl &= ~(uint32_t)NEE_MIS; // diagnostic build: the shadow rays alone (timing only: wrong radiance)
+#elif defined(PTRS_ABL_CONNECT_ONLY) && PTRS_ABL_CONNECT_ONLY == 2
+                    fl &= ~(uint32_t)NEE_SHADOW; // diagnostic build: the MIS rays alone
+#endif
                     if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
                 }
                 cursor += (uint32_t)__popcll(idle);
@@ -628,13 +633,15 @@ __global__ __launch_bounds__(BLOCK) void k_epilogue(DParams R, DScene sc, DPaths
 // loop around it 168 registers cost 24 spilled ones (116 bytes of scratch, each reload a trip to L1 / L2 that 2.7 waves per SIMD do
 // not cover), and at 2 waves without spills the kernel is 2 % faster alone and the three-lane frame 5 % (177.9-179.2 -> 169.3-169.8
 // ms: its workgroups leave room for the other lanes' traversal kernels).  The mirror / glass kernels need 109-135 registers and get
-// their third wave from the LDS budget alone; the Disney kernel with image textures (colonnade) needs 209 and still gains at 168
-// with spills (shade kernels 42.3 -> 39.6 ms); the other Disney / metal / substrate kernels (191-256 registers) stay at 2.
+// their third wave from the LDS budget alone; the Disney kernel with image textures (colonnade) needs 209: at 168 with 68 spilled registers it was
+// faster alone on one lane (shade kernels 42.3 -> 39.6 ms), but with four lanes sharing the machine the 2-wave kernel without scratch wins
+// (colonnade 113.2-113.6 -> 109.9-110.0 ms: no scratch set-up per dispatch, room for the other lanes' traversal waves); the other
+// Disney / metal / substrate kernels (191-256 registers) stay at 2.
 #ifndef PTRS_SHADE_WAVES_MATTE
 #define PTRS_SHADE_WAVES_MATTE 2
 #endif
 #ifndef PTRS_SHADE_WAVES_DISNEY_IMG
-#define PTRS_SHADE_WAVES_DISNEY_IMG 3
+#define PTRS_SHADE_WAVES_DISNEY_IMG 2
 #endif
 template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT == FEAT_SIMPLE) ? PTRS_SHADE_WAVES_MATTE : ((MAT == 4 && FEAT == FEAT_IMG) ? PTRS_SHADE_WAVES_DISNEY_IMG : 2) }; }; // 2: never above 256 registers (one wave per SIMD otherwise)
 
