@@ -195,6 +195,7 @@ PT_HD void draw_vertex(const CTX &X, const DSampler &S, const u4 &stv, bool nee,
 // of the current round out of LDS: the shade kernels are bound by the number of vector-memory instructions in flight, not
 // by bytes).
 struct ShadeCtx {
+    static constexpr bool inf_fallback = true; // light_sample_li may be asked for an InfiniteAreaLight sample
     PT_MEM TriRegs tri(const DScene &sc, int32_t prim, bool want_dp) const { return load_tri_regs(sc.shade + prim, want_dp); }
     PT_MEM void light(const DScene &sc, uint32_t li, DLight &out) const { out = sc.lights[li]; }
     PT_MEM const InfMarginal *inf_marginal(uint32_t) const { return nullptr; }
@@ -298,7 +299,7 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
             ls.p1_err = splat3(0.0f); ls.p1_n = splat3(0.0f);
             ls.wi = xyz(in.pre0); ls.pdf = in.pre0.w; ls.li = xyz(in.pre1);
             ls.p1 = f2u(in.pre1.w) ? s.p + ls.wi * (2.0f * Lt.world_radius) : s.p;
-        } else light_sample_li<FEAT>(sc, Lt, s.p, sp, u_light, ls, X.inf_marginal(li));
+        } else light_sample_li<FEAT, CTX::inf_fallback>(sc, Lt, s.p, sp, u_light, ls, X.inf_marginal(li));
         PT_STAMP(4, f2u(ls.pdf) + f2u(ls.wi.x) + f2u(ls.li.x) + f2u(ls.p1.x))
         f3 A = splat3(0.0f);
         float spdf = 0.0f;

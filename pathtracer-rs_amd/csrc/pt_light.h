@@ -121,7 +121,10 @@ PT_HD bool inf_light_sample(const DScene &sc, const DLight &L, f2 u, f3 &wi, flo
 
 // Light::sample_li.  Returns false when the reference leaves the visibility tester unset
 // (InfiniteAreaLight with map_pdf == 0, light.rs:411-413) -- the reference would panic there.
-template <int FEAT>
+// INF = false: the caller has every InfiniteAreaLight sample from elsewhere (k_env_presample) and never asks for one here -- the walk
+// of the environment map's distribution is then not part of the caller's code (in the 256-register Disney shade kernel it cost 21
+// spilled registers and 12 KB of LDS for the marginal table).
+template <int FEAT, bool INF = true>
 PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const SpawnPair &ref_sp, f2 u, LightSample &o, const InfMarginal *im = nullptr) {
     // (one exit, every field of `o` assigned there from locals: with a return per light kind the optimizer merged the kinds' stores of
     // different fields behind a pointer phi, which kept four floats of the sample in scratch memory -- 20 bytes per lane that cost
@@ -146,7 +149,7 @@ PT_HD bool light_sample_li(const DScene &sc, const DLight &L, f3 ref_p, const Sp
         p1 = p; p1_err = perr; p1_n = n;
         f3 w = -wi;
         li = dot(n, w) > 0.0f ? (L.ke_const ? ld3(L.c) : tex_eval<FEAT>(sc, L.ke_tex, uv, 0.0f, 0.0f, 0.0f, 0.0f)) : splat3(0.0f);
-    } else if (!(FEAT & FEAT_INFINITE)) { ok = false; // unreachable
+    } else if (!(FEAT & FEAT_INFINITE) || !INF) { ok = false; // unreachable
     } else { // infinite area light
         ok = inf_light_sample(sc, L, u, wi, pdf, li, im);
         p1 = ok ? ref_p + wi * (2.0f * L.world_radius) : ref_p;

@@ -665,7 +665,9 @@ struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds, mar
 enum : uint32_t { SH_MARG_N = 1024, SH_MARG_WORDS = 3 * SH_MARG_N + 8 }; // row integrals [nv] | their cdf [nv + 1] | the cdf's guide [guide_v + 1], nv and guide_v <= 1024 // Sobol' window [sob_lo, sob_lo + sob_n), nibbles staged per dimension
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 PT_HD uint32_t sob_stride(uint32_t nib) { return nib * 16u + 4u; } // words per dimension; + 4: consecutive dimensions start 4 banks apart
+template <bool ENVPRE = false>
 struct ShadeCtxLds {
+    static constexpr bool inf_fallback = !ENVPRE; // ENVPRE: the scene's one InfiniteAreaLight is presampled (k_env_presample), shade_item never walks its distribution itself
     lds_u32 *sob; lds_v4 *tris, *lights; ShadeLdsCfg cfg; InfMarginal marg;
     __device__ inline const InfMarginal *inf_marginal(uint32_t li) const { return li == cfg.marg_li ? &marg : nullptr; }
     __device__ inline bool presampled(uint32_t li) const { return li == cfg.pre_li; }
@@ -726,14 +728,15 @@ struct ShadeCtxLds {
     }
 };
 
-template <int MAT, int FEAT>
+template <int MAT, int FEAT, bool ENVPRE>
 __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
     constexpr uint32_t NPF = (FEAT & FEAT_INFINITE) ? 7u : 5u; // + the vertex's presampled environment-light sample
     __shared__ v4 lds_pf[NPF * BLOCK]; // the next item's path state per thread, filled by LDS-DMA
     __shared__ uint32_t lds_sob[SH_SOB_WORDS];
     __shared__ v4 lds_tri[SH_TRI_V4];
     __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
-    __shared__ float lds_marg[(FEAT & FEAT_INFINITE) ? SH_MARG_WORDS : 1];
+    constexpr bool MARG = (FEAT & FEAT_INFINITE) && !ENVPRE; // the in-kernel walk of the environment light's distribution needs its marginal tables
+    __shared__ float lds_marg[MARG ? SH_MARG_WORDS : 1];
     bool err_dim = false;
     if (round_is_dead(Q, it)) return;
     {
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         if (cfg.tri_lds) { const v4 *g = reinterpret_cast<const v4 *>(sc.shade); for (uint32_t i = threadIdx.x; i < sc.n_prims * SH_TRI_REC_V4; i += BLOCK) lds_tri[i] = g[i]; }
         const v4 *gl = reinterpret_cast<const v4 *>(sc.lights);
         for (uint32_t i = threadIdx.x; i < cfg.n_lights_lds * SH_LIGHT_V4; i += BLOCK) lds_light[i] = gl[i];
-        if ((FEAT & FEAT_INFINITE) && cfg.marg_li != 0xffffffffu) { // the environment light's marginal distribution: 12 KB that every light sample walks first
+        if (MARG && cfg.marg_li != 0xffffffffu) { // the environment light's marginal distribution: 12 KB that every light sample walks first
             const DLight &Le = sc.lights[cfg.marg_li];
             const uint32_t nv = (uint32_t)Le.nv, gv = Le.guide_v;
             for (uint32_t i = threadIdx.x; i < nv; i += BLOCK) lds_marg[i] = sc.distdata[Le.fint_off + i];
@@ -751,8 +754,9 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
         }
     }
     __syncthreads(); // the only barrier: the tables are staged once per workgroup, then its four waves work through segments on their own
-    ShadeCtxLds X; X.sob = (lds_u32 *)lds_sob; X.tris = (lds_v4 *)lds_tri; X.lights = (lds_v4 *)lds_light; X.cfg = cfg;
-    X.marg.func = lds_marg; X.marg.cdf = lds_marg + ((FEAT & FEAT_INFINITE) ? SH_MARG_N : 0); X.marg.guide = lds_marg + ((FEAT & FEAT_INFINITE) ? 2 * SH_MARG_N + 1 : 0);
+    ShadeCtxLds<ENVPRE> X; X.sob = (lds_u32 *)lds_sob; X.tris = (lds_v4 *)lds_tri; X.lights = (lds_v4 *)lds_light; X.cfg = cfg;
+    if (!MARG) X.cfg.marg_li = 0xffffffffu;
+    X.marg.func = lds_marg; X.marg.cdf = lds_marg + (MARG ? SH_MARG_N : 0); X.marg.guide = lds_marg + (MARG ? 2 * SH_MARG_N + 1 : 0);
 #ifdef PTRS_STAMPS
     unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_presample(DSampler S, DScene sc, 
     }
     __syncthreads();
     InfMarginal marg; marg.func = lds_marg; marg.cdf = lds_marg + SH_MARG_N; marg.guide = lds_marg + 2 * SH_MARG_N + 1;
-    ShadeCtxLds X; X.sob = (lds_u32 *)lds_sob; X.tris = nullptr; X.lights = nullptr; X.cfg = cfg; X.marg = marg;
+    ShadeCtxLds<false> X; X.sob = (lds_u32 *)lds_sob; X.tris = nullptr; X.lights = nullptr; X.cfg = cfg; X.marg = marg;
     const uint32_t lane = __lane_id();
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
         for (int m = 0; m < 6; ++m) {
@@ -1342,17 +1346,25 @@ struct HipBackend {
         return c;
     }
     typedef void (*ShadeFn)(DParams, DSampler, DCamera, DScene, DPaths, DQueues, uint32_t, uint32_t, ShadeLdsCfg, uint32_t, uint32_t *);
-    template <int FEAT> ShadeFn shade_fn_t(int kind) {
+    template <int FEAT, bool ENVPRE> ShadeFn shade_fn_t(int kind) {
         switch (kind) {
-            case 0: return k_shade<0, FEAT>;
-            case 1: return k_shade<1, FEAT>;
-            case 2: return k_shade<2, FEAT>;
-            case 3: return k_shade<3, FEAT>;
-            case 4: return k_shade<4, FEAT>;
-            default: return k_shade<5, FEAT>;
+            case 0: return k_shade<0, FEAT, ENVPRE>;
+            case 1: return k_shade<1, FEAT, ENVPRE>;
+            case 2: return k_shade<2, FEAT, ENVPRE>;
+            case 3: return k_shade<3, FEAT, ENVPRE>;
+            case 4: return k_shade<4, FEAT, ENVPRE>;
+            default: return k_shade<5, FEAT, ENVPRE>;
         }
     }
-    ShadeFn shade_fn(int kind) { return feat == FEAT_SIMPLE ? shade_fn_t<FEAT_SIMPLE>(kind) : (feat == FEAT_IMG ? shade_fn_t<FEAT_IMG>(kind) : (feat == FEAT_IMG_ENV ? shade_fn_t<FEAT_IMG_ENV>(kind) : shade_fn_t<FEAT_FULL>(kind))); }
+    // (ENVPRE: every InfiniteAreaLight sample of the render comes from k_env_presample -- the scene has one such light and it is the
+    // presampled one -- so the shade kernels are built without the walk of its distribution)
+    bool env_presampled_only() const { return presample_li() != 0xffffffffu && ps->H.inf_lights.size() == 1; }
+    ShadeFn shade_fn(int kind) {
+        if (feat == FEAT_SIMPLE) return shade_fn_t<FEAT_SIMPLE, false>(kind);
+        if (feat == FEAT_IMG) return shade_fn_t<FEAT_IMG, false>(kind);
+        if (feat == FEAT_IMG_ENV) return env_presampled_only() ? shade_fn_t<FEAT_IMG_ENV, true>(kind) : shade_fn_t<FEAT_IMG_ENV, false>(kind);
+        return env_presampled_only() ? shade_fn_t<FEAT_FULL, true>(kind) : shade_fn_t<FEAT_FULL, false>(kind);
+    }
     // the environment light k_env_presample serves: one InfiniteAreaLight whose marginal tables fit the LDS area, Sobol' sampler
     uint32_t presample_li() const {
         if (!opt.env_presample || !(feat & FEAT_INFINITE) || S.kind != PTRS_SAMPLER_SOBOL || ps->H.inf_lights.empty()) return 0xffffffffu;
