@@ -4,7 +4,7 @@
 //   nodes   : 32-byte BVH nodes, depth-first (first child = i+1), two 16-byte loads per node.
 //   tris    : 48-byte leaf-ordered triangle records (3 x 16-byte loads, no index indirection).
 //   shade   : 160-byte per-triangle shading records (positions, normals, uvs, tangents, ids).
-//   paths   : structure-of-arrays of 16-byte vectors indexed by path slot; queues of slot ids.
+//   paths   : structure-of-arrays of 16-byte vectors in queue order (what travels with a path) or indexed by path slot (what it keeps); queues of slot ids.
 #pragma once
 #include "pt_vec.h"
 

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DScene sc, DPaths P, DQueues 
 }
 
 // The epilogue of one queue segment, full waves: emission / environment / depth cut (integrator.rs:418-431) and material
-// bucketing, in queue order (the shade stage's state gathers coalesce only while a segment keeps its paths in slot order).
+// bucketing, in queue order: hits, state words and path slots of 64 consecutive positions per step.
 template <int FEAT>
 __device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t G, uint32_t s) {
     const uint32_t lane = __lane_id();
@@ -661,7 +661,7 @@ template <int MAT, int FEAT> struct ShadeWaves { enum { N = (MAT == 0 && FEAT ==
 #endif
 enum : uint32_t { SH_SOB_WORDS = PTRS_SH_SOB_WORDS, SH_TRI_V4 = PTRS_SH_TRI_V4, SH_LIGHTS = 16, SH_LIGHT_V4 = sizeof(DLight) / 16, SH_TRI_REC_V4 = sizeof(DTriShade) / 16 };
 static_assert(sizeof(DLight) % 16 == 0 && sizeof(DTriShade) % 16 == 0, "records are staged as 16-byte vectors");
-struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds, marg_li, pre_li; }; // pre_li: the environment light whose samples k_env_presample has left in nee0 / nee1 (0xffffffff: none) // marg_li: the environment light whose marginal tables are staged (0xffffffff: none)
+struct ShadeLdsCfg { uint32_t sob_lo, sob_n, sob_nib, tri_lds, n_lights_lds, marg_li, pre_li; }; // pre_li: the environment light whose samples k_env_presample has left in pre0 / pre1 (0xffffffff: none) // marg_li: the environment light whose marginal tables are staged (0xffffffff: none)
 enum : uint32_t { SH_MARG_N = 1024, SH_MARG_WORDS = 3 * SH_MARG_N + 8 }; // row integrals [nv] | their cdf [nv + 1] | the cdf's guide [guide_v + 1], nv and guide_v <= 1024 // Sobol' window [sob_lo, sob_lo + sob_n), nibbles staged per dimension
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 PT_HD uint32_t sob_stride(uint32_t nib) { return nib * 16u + 4u; } // words per dimension; + 4: consecutive dimensions start 4 banks apart
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
 // direction, pdf and radiance do not depend on the shading point: a chain of ~8 dependent reads (the marginal walk, the row's guide and
 // cdf, the map's texels) that the shade kernels used to make at 2 waves per SIMD with 250 registers live around it.  Here it runs
 // with a third of the registers and the latency of one vertex hidden behind the others'; the shade kernel receives (wi, pdf | Li, valid)
-// in nee0 / nee1 with the rest of the vertex's state.
+// in pre0 / pre1 (by the vertex's position in the extension queue) with the rest of the vertex's state.
 template <int FEAT>
 __global__ __launch_bounds__(BLOCK) void k_env_presample(DSampler S, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t nee_kinds, uint32_t env_li, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
     __shared__ float lds_marg[SH_MARG_WORDS];

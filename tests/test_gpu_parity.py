@@ -259,6 +259,8 @@ def test_full_size_properties(ptrs):
     a = cam.film.pixels.copy()
     st = integ.last_stats
     assert st.samples == 1028 * 1028 * 16 and st.rays_extension >= st.samples
+    assert st.lanes == 4 and st.passes == 4 and st.queue_segments % 8 == 0 and st.grid_pct == 100  # the default launch policy for a job of this size: four lanes of CUs x 8 wave-segments
+    assert 0.0 < st.ms_enqueue <= st.ms_total  # the host is done enqueuing long before the device is through
     w = a["weight"][8:-8, 8:-8]
     assert np.isfinite(a["rgb"]).all() and (a["rgb"] >= 0).all()
     assert np.allclose(w, np.median(w), rtol=0.35) and w.min() > 0
