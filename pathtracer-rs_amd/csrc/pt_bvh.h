@@ -20,12 +20,26 @@ struct GeomGlobal {
     const v4 *nodesv; const DTri *tris; // nodesv: the scene's pair nodes (4 vectors each) or quad nodes (8 vectors each)
     PT_MEM void node(uint32_t i, v4 &a, v4 &b, v4 &c, v4 &d) const { const v4 *q = nodesv + 4u * i; a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
     PT_MEM void node8(uint32_t i, v4 *o) const { const v4 *q = nodesv + 8u * i; for (int k = 0; k < 8; ++k) o[k] = q[k]; }
+    // quad node i: the near and far plane vectors of a ray whose per-axis near-plane byte offsets are (px, py, pz) (0 | 16, 32 | 48, 64 | 80:
+    // the far vector is the other one of the pair), the references, the axes word
+    PT_MEM void quad_load(uint32_t i, uint32_t px, uint32_t py, uint32_t pz, v4 &xn, v4 &xf, v4 &yn, v4 &yf, v4 &zn, v4 &zf, v4 &refs, v4 &meta) const {
+        const char *b = reinterpret_cast<const char *>(nodesv);
+        const uint32_t off = i * 128u; // 32-bit byte offsets from one base: the six plane reads cost an add (and a xor) each, not a 64-bit address
+        xn = *reinterpret_cast<const v4 *>(b + (size_t)(off + px)); xf = *reinterpret_cast<const v4 *>(b + (size_t)((off + px) ^ 16u));
+        yn = *reinterpret_cast<const v4 *>(b + (size_t)(off + py)); yf = *reinterpret_cast<const v4 *>(b + (size_t)((off + py) ^ 16u));
+        zn = *reinterpret_cast<const v4 *>(b + (size_t)(off + pz)); zf = *reinterpret_cast<const v4 *>(b + (size_t)((off + pz) ^ 16u));
+        refs = *reinterpret_cast<const v4 *>(b + (size_t)(off + 96u)); meta = *reinterpret_cast<const v4 *>(b + (size_t)(off + 112u));
+    }
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { const v4 *q = reinterpret_cast<const v4 *>(tris + k); a = q[0]; b = q[1]; c = q[2]; }
 };
 struct GeomLocal {
     const v4 *nodes4; const v4 *tris4;
     PT_MEM void node(uint32_t i, v4 &a, v4 &b, v4 &c, v4 &d) const { const v4 *q = nodes4 + 4u * i; a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
     PT_MEM void node8(uint32_t i, v4 *o) const { const v4 *q = nodes4 + 8u * i; for (int k = 0; k < 8; ++k) o[k] = q[k]; }
+    PT_MEM void quad_load(uint32_t i, uint32_t px, uint32_t py, uint32_t pz, v4 &xn, v4 &xf, v4 &yn, v4 &yf, v4 &zn, v4 &zf, v4 &refs, v4 &meta) const {
+        const v4 *q = nodes4 + 8u * i;
+        xn = q[px >> 4]; xf = q[(px >> 4) ^ 1u]; yn = q[py >> 4]; yf = q[(py >> 4) ^ 1u]; zn = q[pz >> 4]; zf = q[(pz >> 4) ^ 1u]; refs = q[6]; meta = q[7];
+    }
     PT_MEM void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { a = tris4[3u * k]; b = tris4[3u * k + 1u]; c = tris4[3u * k + 2u]; }
 };
 
@@ -53,15 +67,22 @@ PT_HD bool slab_finish(float tx_min, float ty_min, float tz_min, float tx_max, f
 // Bounds3::intersect_p_precomp (bounds.rs:190-232) on explicit box corners, split in two: everything
 // that does not depend on ray.t_max (the per-axis interval tests and `t_max_box > 0`) is decided here
 // and the entry distance returned; the caller finishes the test with `t_entry < ray.t_max`.
+// (slab_planes: the same from the planes the ray meets first / last on each axis -- bounds[dir_is_neg] / bounds[1 - dir_is_neg] of
+// bounds.rs:196-203 -- already picked: the quad nodes keep their planes per axis, and a lane READS the near and the far vector of its
+// ray's signs instead of selecting every plane after the fetch)
+PT_HD bool slab_planes(float nx, float ny, float nz, float fx, float fy, float fz, f3 o, f3 inv, float &t_entry);
 PT_HD bool slab_entry6(float minx, float miny, float minz, float maxx, float maxy, float maxz, f3 o, f3 inv, const bool neg[3], float &t_entry) {
+    return slab_planes(neg[0] ? maxx : minx, neg[1] ? maxy : miny, neg[2] ? maxz : minz, neg[0] ? minx : maxx, neg[1] ? miny : maxy, neg[2] ? minz : maxz, o, inv, t_entry);
+}
+PT_HD bool slab_planes(float nx, float ny, float nz, float fx, float fy, float fz, f3 o, f3 inv, float &t_entry) {
     const float k = 1.0f + 2.0f * gamma_err(3);
-    float t_min = ((neg[0] ? maxx : minx) - o.x) * inv.x;
-    float t_mx = ((neg[0] ? minx : maxx) - o.x) * inv.x;
-    const float ty_min = ((neg[1] ? maxy : miny) - o.y) * inv.y;
-    float ty_max = ((neg[1] ? miny : maxy) - o.y) * inv.y;
+    float t_min = (nx - o.x) * inv.x;
+    float t_mx = (fx - o.x) * inv.x;
+    const float ty_min = (ny - o.y) * inv.y;
+    float ty_max = (fy - o.y) * inv.y;
     t_mx *= k; ty_max *= k;
-    const float tz_min = ((neg[2] ? maxz : minz) - o.z) * inv.z;
-    float tz_max = ((neg[2] ? minz : maxz) - o.z) * inv.z;
+    const float tz_min = (nz - o.z) * inv.z;
+    float tz_max = (fz - o.z) * inv.z;
     tz_max *= k;
 #if defined(__HIP_DEVICE_COMPILE__)
     return slab_finish(t_min, ty_min, tz_min, t_mx, ty_max, tz_max, t_entry);
@@ -193,19 +214,23 @@ PT_HD bool bvh_trace_pair(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
 // (an inner node, a leaf, or REF_NONE when the stack has run dry).
 PT_HD uint32_t neg_bits3(const bool neg[3]) { const uint32_t b = (neg[0] ? 1u : 0u) | (neg[1] ? 2u : 0u) | (neg[2] ? 4u : 0u); return b | (b << 8) | (b << 16); } // the ray's sign bits, once per byte (DNode4::pad[0])
 template <bool ANY, class Stack, class Geom>
-PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes, uint32_t negbits3) {
-    v4 q[8];
-    G.node8(cur, q);
-    uint32_t r0 = f2u(q[6].x), r1 = f2u(q[6].y), r2 = f2u(q[6].z), r3 = f2u(q[6].w);
-    const uint32_t axes = f2u(q[7].x);
+PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, uint32_t px, uint32_t py, uint32_t pz, float t_max, Stack &stack, uint32_t &n_nodes, uint32_t negbits3) {
+    // The node keeps its planes per axis: vectors (x lower, x upper, y lower, y upper, z lower, z upper), each with the four slots'
+    // values.  Which of a pair the ray meets first is a constant of the ray (px, py, pz: the byte offsets of its near vectors), so the
+    // lane reads (near, far) per axis and the four slab tests need no select: the quad visit of round 2 spent 24 v_cndmask_b32 -- a
+    // half-rate instruction on gfx950 -- on picking planes after the fetch.
+    v4 xn, xf, yn, yf, zn, zf, rf, mt;
+    G.quad_load(cur, px, py, pz, xn, xf, yn, yf, zn, zf, rf, mt);
+    uint32_t r0 = f2u(rf.x), r1 = f2u(rf.y), r2 = f2u(rf.z), r3 = f2u(rf.w);
+    const uint32_t axes = f2u(mt.x);
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
     // (an empty slot's box is (+inf, -inf): its test fails by itself)
-    bool h0 = slab_entry6(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, o, inv, neg, t0); h0 = h0 & (t0 < t_max);
-    bool h1 = slab_entry6(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, o, inv, neg, t1); h1 = h1 & (t1 < t_max);
-    bool h2 = slab_entry6(q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, o, inv, neg, t2); h2 = h2 & (t2 < t_max);
-    bool h3 = slab_entry6(q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, o, inv, neg, t3); h3 = h3 & (t3 < t_max);
+    bool h0 = slab_planes(xn.x, yn.x, zn.x, xf.x, yf.x, zf.x, o, inv, t0); h0 = h0 & (t0 < t_max);
+    bool h1 = slab_planes(xn.y, yn.y, zn.y, xf.y, yf.y, zf.y, o, inv, t1); h1 = h1 & (t1 < t_max);
+    bool h2 = slab_planes(xn.z, yn.z, zn.z, xf.z, yf.z, zf.z, o, inv, t2); h2 = h2 & (t2 < t_max);
+    bool h3 = slab_planes(xn.w, yn.w, zn.w, xf.w, yf.w, zf.w, o, inv, t3); h3 = h3 & (t3 < t_max);
     n_nodes += (axes >> 12) & 7u;
-    const uint32_t sx = negbits3 & f2u(q[7].y); // (the split axes as one-hot bytes against the ray's sign bits: = ax < 3 && neg[ax] etc.)
+    const uint32_t sx = negbits3 & f2u(mt.y); // (the split axes as one-hot bytes against the ray's sign bits: = ax < 3 && neg[ax] etc.)
     const bool sw = (sx & 0xffu) != 0u, swa = (sx & 0xff00u) != 0u, swb = (sx & 0xff0000u) != 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__builtin_amdgcn_ballot_w64((axes & 0x100u) != 0u) != 0ull) // (rare: the four selects run only in waves that meet such a node)
@@ -232,9 +257,13 @@ PT_HD void quad_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg
 }
 
 template <bool QUAD, bool ANY, class Stack, class Geom>
-PT_HD void node_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes, uint32_t negbits3) {
-    if (QUAD) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes, negbits3); else pair_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes);
+PT_HD void node_visit(const Geom &G, uint32_t &cur, f3 o, f3 inv, const bool neg[3], float t_max, Stack &stack, uint32_t &n_nodes, uint32_t negbits3, uint32_t px, uint32_t py, uint32_t pz) {
+    if (QUAD) quad_visit<ANY>(G, cur, o, inv, px, py, pz, t_max, stack, n_nodes, negbits3); else pair_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes);
 }
+// the byte offsets of a ray's near-plane vectors inside a quad node (the far one of an axis is the other of its pair: offset ^ 16)
+PT_HD uint32_t quad_near_x(const bool neg[3]) { return neg[0] ? 16u : 0u; }
+PT_HD uint32_t quad_near_y(const bool neg[3]) { return neg[1] ? 48u : 32u; }
+PT_HD uint32_t quad_near_z(const bool neg[3]) { return neg[2] ? 80u : 64u; }
 
 // Quad-node traversal (DNode4): one fetch covers two levels of the binary tree.  Slots are visited in the order the
 // binary traversal would reach them -- near child's (near, far) grandchildren, then the far child's -- and every
@@ -254,7 +283,7 @@ PT_HD bool bvh_trace_quad(const Geom &G, const DScene &sc, f3 o, f3 d, float t_m
     bool hit = false;
     const uint32_t nb3 = neg_bits3(neg);
     while (cur != REF_NONE) {
-        while (cur != REF_NONE && !(cur & REF_LEAF)) quad_visit<ANY>(G, cur, o, inv, neg, t_max, stack, n_nodes, nb3);
+        while (cur != REF_NONE && !(cur & REF_LEAF)) quad_visit<ANY>(G, cur, o, inv, quad_near_x(neg), quad_near_y(neg), quad_near_z(neg), t_max, stack, n_nodes, nb3);
         if (cur == REF_NONE) break;
         if (leaf_test<ANY, ALPHA>(G, sc, cur, o, shear, t_max, out, hit, n_tris)) return true;
         cur = REF_NONE;

@@ -344,13 +344,13 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
         struct Conv {
             const std::vector<DNode> &n; std::vector<DNode4> &out;
             static void set_slot(DNode4 &d, int s, const DNode &nd, uint32_t ref) {
-                float *b = d.box + 6 * s;
-                b[0] = nd.pmin[0]; b[1] = nd.pmin[1]; b[2] = nd.pmin[2]; b[3] = nd.pmax0; b[4] = nd.pmax1; b[5] = nd.pmax2;
+                const float lo[3] = {nd.pmin[0], nd.pmin[1], nd.pmin[2]}, hi[3] = {nd.pmax0, nd.pmax1, nd.pmax2};
+                for (int a = 0; a < 3; ++a) { d.box[(2 * a) * 4 + s] = lo[a]; d.box[(2 * a + 1) * 4 + s] = hi[a]; } // per axis: the four slots' lower planes, then their upper planes
                 d.ref[s] = ref;
             }
             // an empty slot holds the box no ray can enter (min = +inf, max = -inf: its slab test ends with t_max_box = -inf > 0 false for every
             // finite origin and any direction, infinite reciprocals included), so traversal needs no test for REF_NONE
-            static DNode4 blank() { DNode4 d; std::memset(&d, 0, sizeof(d)); for (int s = 0; s < 4; ++s) { d.ref[s] = REF_NONE; for (int k = 0; k < 3; ++k) { d.box[6 * s + k] = PT_INF; d.box[6 * s + 3 + k] = -PT_INF; } } return d; }
+            static DNode4 blank() { DNode4 d; std::memset(&d, 0, sizeof(d)); for (int s = 0; s < 4; ++s) { d.ref[s] = REF_NONE; for (int k = 0; k < 3; ++k) { d.box[(2 * k) * 4 + s] = PT_INF; d.box[(2 * k + 1) * 4 + s] = -PT_INF; } } return d; }
             // reference to a leaf range; ranges longer than REF_MAX_LEAF (only possible when many centroids coincide)
             // become quad nodes whose slots are consecutive chunks sharing the leaf's box, visited in order and
             // popped without the entry re-test (the reference tests such a leaf's box once)

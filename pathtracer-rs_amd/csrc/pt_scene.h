@@ -33,7 +33,9 @@ static_assert(sizeof(DNode2) == 64, "node2");
 
 // Quad node: TWO levels of the binary tree in one 128-byte record (8 x 16 B = one L2 line).  Slots 0,1 are the
 // children of the node's first child A, slots 2,3 those of its second child B; when A (or B) is itself a leaf it
-// occupies slot 0 (or 2) and slot 1 (or 3) is REF_NONE.  Box s = floats [6s, 6s+6) = min xyz, max xyz.
+// occupies slot 0 (or 2) and slot 1 (or 3) is REF_NONE.  The boxes are stored PER AXIS: box[(2 a + u) * 4 + s] = lower (u = 0) / upper
+// (u = 1) plane of slot s on axis a -- six vectors of four slots each, so that a ray reads, per axis, the vector of the planes it meets
+// first and the vector of those it meets last (by the sign of its direction) instead of selecting 24 planes after the fetch.
 // axes: bits 0-1 split axis of the node, 2-3 of A, 4-5 of B (3 = never swap); bit 8: entries stacked from this node
 // are popped without the entry-distance re-test (chunks of one over-long leaf share the leaf's box); bits 12-14: number of
 // occupied slots.  An empty slot (ref REF_NONE) holds the box (+inf, -inf), which no ray enters.

@@ -149,6 +149,24 @@ struct GeomTop {
         if (i < ktop) { lds_v4 *q = top + TOP_LDS_STRIDE * i; for (int k = 0; k < 8; ++k) o[k] = lds_ld(q + k); }
         else { const v4 *q = nodesv + 8u * i; for (int k = 0; k < 8; ++k) o[k] = q[k]; }
     }
+    // (see GeomGlobal::quad_load; the top of the tree out of LDS, records 9 vectors apart)
+    __device__ inline void quad_load(uint32_t i, uint32_t px, uint32_t py, uint32_t pz, v4 &xn, v4 &xf, v4 &yn, v4 &yf, v4 &zn, v4 &zf, v4 &refs, v4 &meta) const {
+        if (i < ktop) {
+            typedef __attribute__((address_space(3))) const char lds_c;
+            lds_c *b = (lds_c *)top + i * (TOP_LDS_STRIDE * 16u);
+            xn = lds_ld((lds_v4 *)(b + px)); xf = lds_ld((lds_v4 *)(b + (px ^ 16u)));
+            yn = lds_ld((lds_v4 *)(b + py)); yf = lds_ld((lds_v4 *)(b + (py ^ 16u)));
+            zn = lds_ld((lds_v4 *)(b + pz)); zf = lds_ld((lds_v4 *)(b + (pz ^ 16u)));
+            refs = lds_ld((lds_v4 *)(b + 96u)); meta = lds_ld((lds_v4 *)(b + 112u));
+        } else {
+            const char *b = reinterpret_cast<const char *>(nodesv);
+            const uint32_t off = i * 128u;
+            xn = *reinterpret_cast<const v4 *>(b + (size_t)(off + px)); xf = *reinterpret_cast<const v4 *>(b + (size_t)((off + px) ^ 16u));
+            yn = *reinterpret_cast<const v4 *>(b + (size_t)(off + py)); yf = *reinterpret_cast<const v4 *>(b + (size_t)((off + py) ^ 16u));
+            zn = *reinterpret_cast<const v4 *>(b + (size_t)(off + pz)); zf = *reinterpret_cast<const v4 *>(b + (size_t)((off + pz) ^ 16u));
+            refs = *reinterpret_cast<const v4 *>(b + (size_t)(off + 96u)); meta = *reinterpret_cast<const v4 *>(b + (size_t)(off + 112u));
+        }
+    }
     __device__ inline void node(uint32_t, v4 &, v4 &, v4 &, v4 &) const {}
     __device__ inline void tri(uint32_t k, v4 &a, v4 &b, v4 &c) const { const v4 *q = reinterpret_cast<const v4 *>(tris + k); a = q[0]; b = q[1]; c = q[2]; }
 };
@@ -385,19 +403,19 @@ __device__ inline GeomTop stage_top(const DScene &sc, v4 *lds, bool top) {
 // Per-lane ray state of the refill kernels: plain scalars on purpose (a struct with the sign array in it made hipcc
 // produce a 20 % slower loop).
 #define RF_DECL f3 r_o = mk3(0, 0, 0), r_inv = mk3(1, 1, 1); bool r_neg[3] = {false, false, false}; RayShear r_shear; r_shear.kz = 2; r_shear.sx = r_shear.sy = 0.0f; r_shear.sz = 1.0f; \
-                float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE, r_nb3 = 0;
+                float r_tmax = 0.0f; bool r_hit = false; HitRec r_h; r_h.prim = -1; r_h.t = 0.0f; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; uint32_t r_cur = REF_NONE, r_nb3 = 0, r_px = 0, r_py = 32, r_pz = 64;
 #define RF_START(O, D, TMAX) { r_o = (O); const f3 d_ = (D); r_tmax = (TMAX); r_inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z); \
-                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_nb3 = neg_bits3(r_neg); r_shear = ray_shear_inv(d_, r_inv); \
+                r_neg[0] = r_inv.x < 0.0f; r_neg[1] = r_inv.y < 0.0f; r_neg[2] = r_inv.z < 0.0f; r_nb3 = neg_bits3(r_neg); r_px = quad_near_x(r_neg); r_py = quad_near_y(r_neg); r_pz = quad_near_z(r_neg); r_shear = ray_shear_inv(d_, r_inv); \
                 r_h.prim = -1; r_h.t = r_tmax; r_h.b0 = r_h.b1 = r_h.b2 = 0.0f; r_h.flags = 0; r_hit = false; r_cur = 0; }
 
 template <bool VOTE, bool QUAD, bool ALPHA, class Stack, class Geom>
-__device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], uint32_t r_nb3, const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
+__device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur, f3 r_o, f3 r_inv, const bool r_neg[3], uint32_t r_nb3, uint32_t r_px, uint32_t r_py, uint32_t r_pz, const RayShear &r_shear, float &r_tmax, HitRec &r_h, bool &r_hit,
                                Stack &stk, uint32_t &nn, uint32_t &nt, bool any_rt, StepCount &sc_n) {
     if (VOTE) {
         const bool at_node = (int32_t)r_cur >= 0, at_leaf = (int32_t)r_cur < -1; // leaf references have bit 31 set; lanes without a ray hold REF_NONE = -1
         const uint32_t n_node = rfl((uint32_t)__popcll(__ballot(at_node))), n_leaf = rfl((uint32_t)__popcll(__ballot(at_leaf))); // (scalar registers: the comparison is an s_cmp)
         if (n_node >= n_leaf) {
-            if (at_node) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn, r_nb3); }
+            if (at_node) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn, r_nb3, r_px, r_py, r_pz); }
         } else if (at_leaf) {
             PT_COUNT_TRI(sc_n, 1u)
             const bool done = leaf_step<ALPHA>(G, sc, r_cur, r_o, r_shear, r_tmax, r_h, r_hit, nt, any_rt);
@@ -405,7 +423,7 @@ __device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur,
         }
         return;
     }
-    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn, r_nb3); }
+    while (r_cur != REF_NONE && !(r_cur & REF_LEAF)) { PT_COUNT_NODE(sc_n) node_visit<QUAD, false>(G, r_cur, r_o, r_inv, r_neg, r_tmax, stk, nn, r_nb3, r_px, r_py, r_pz); }
     if (r_cur != REF_NONE) {
 #ifdef PTRS_STEP_COUNTERS
         { const uint32_t k = ((r_cur >> REF_COUNT_SHIFT) & 15u) + 1u; uint32_t kmax = k; for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)kmax, off); kmax = o > kmax ? o : kmax; } PT_COUNT_TRI(sc_n, kmax) } // (an upper bound, diagnostic only)
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
             if (!__any(has)) break; // every ray of the segment is retired
             do { // steps until enough lanes are through their rays: only then is there something to retire or refill
                 if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
-                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_px, r_py, r_pz, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
             // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
             // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
             // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
@@ -557,7 +575,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
             if (!__any(has)) break;
             do {
                 if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
-                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_px, r_py, r_pz, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
             } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh)); // (see k_extend_rf)
         }
         // records with a MIS ray are resolved behind the wave's last ray (see k_extend_rf's epilogue), unless fused_resolve = 0 leaves them to k_resolve
