@@ -390,6 +390,7 @@ inline int build_host_scene(const PtrsSceneDesc &d, HostScene &H, std::string &e
             DNode4 d = Conv::blank(); Conv::set_slot(d, 0, H.nodes[0], root); d.axes = 3u | (3u << 2) | (3u << 4);
             H.nodes4.insert(H.nodes4.begin(), d);
         }
+        if (H.nodes4.size() >= (1u << 25)) return bad("too many quad nodes for 32-bit node offsets (2^25 x 128 bytes)"); // GeomGlobal::quad_load
         for (DNode4 &d : H.nodes4) { uint32_t c = 0; for (int sl = 0; sl < 4; ++sl) c += d.ref[sl] != REF_NONE ? 1u : 0u; d.axes = (d.axes & 0xfffu) | (c << 12); } // bits 12-14: occupied slots (the boxes-tested statistic)
         // pad[0]: the three split axes once more as one-hot bytes (bit a of byte k set when split k runs along axis a, 0 = never swap): with the
         // ray's sign bits replicated into three bytes, `swap split k` is one AND and one compare instead of an indexed read of the sign array
