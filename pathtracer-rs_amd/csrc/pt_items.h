@@ -468,17 +468,22 @@ PT_HD ShadeResult shade_dispatch(int bucket, const DParams &R, const DSampler &S
 // One sample's contribution to output pixel (x, y): FilmTile::add_sample (film.rs:60-106) seen from the
 // pixel.  pf = p_film of the sample, L its radiance; returns false when the pixel is outside the sample's
 // filter footprint.
-PT_HD bool film_weight(float pfx, float pfy, int32_t x, int32_t y, const float *table, float &w) {
+// (the weight of a pixel inside the sample's footprint; pdx = p_film.x - 0.5, pdy likewise)
+PT_HD float film_weight_inside(float pdx, float pdy, int32_t x, int32_t y, const float *table) {
     const float radius = 2.0f, inv_r = 1.0f / radius;
-    const float pdx = pfx - 0.5f, pdy = pfy - 0.5f;
-    const int32_t p0x = (int32_t)ceil_(pdx - radius), p0y = (int32_t)ceil_(pdy - radius);
-    const int32_t p1x = (int32_t)(floor_(pdx + radius) + 1.0f), p1y = (int32_t)(floor_(pdy + radius) + 1.0f);
-    if (x < p0x || x >= p1x || y < p0y || y >= p1y) return false;
     const float fx = fabs_(((float)x - pdx) * inv_r * 16.0f);
     const float fy = fabs_(((float)y - pdy) * inv_r * 16.0f);
     int32_t ix = (int32_t)floor_(fx); if (ix > 15) ix = 15;
     int32_t iy = (int32_t)floor_(fy); if (iy > 15) iy = 15;
-    w = table[iy * 16 + ix];
+    return table[iy * 16 + ix];
+}
+PT_HD bool film_weight(float pfx, float pfy, int32_t x, int32_t y, const float *table, float &w) {
+    const float radius = 2.0f;
+    const float pdx = pfx - 0.5f, pdy = pfy - 0.5f;
+    const int32_t p0x = (int32_t)ceil_(pdx - radius), p0y = (int32_t)ceil_(pdy - radius);
+    const int32_t p1x = (int32_t)(floor_(pdx + radius) + 1.0f), p1y = (int32_t)(floor_(pdy + radius) + 1.0f);
+    if (x < p0x || x >= p1x || y < p0y || y >= p1y) return false;
+    w = film_weight_inside(pdx, pdy, x, y, table);
     return true;
 }
 

@@ -933,12 +933,17 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_counts(const uint32_t *__restr
 // fetched 102 GB per frame).  Same sums, same order as film_item.
 __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P, const float *__restrict__ table, v4 *film, int32_t y0, int32_t y1, int32_t tiles_x) {
     __shared__ float tab[256];
-    __shared__ v4 s_a[400]; __shared__ float s_lb[400]; // p_film.xy, L.rg | L.b: one 16-byte and one 4-byte LDS read per candidate
+    __shared__ v4 s_a[400]; __shared__ float s_lb[400]; // p_film.xy - 0.5, L.rg | L.b: one 16-byte and one 4-byte LDS read per candidate that contributes
+    // The sample's footprint [p0x, p1x) x [p0y, p1y) (film.rs:66-73) against the tile, worked out ONCE per staged sample: bit c set when
+    // the tile's column c is inside, bit 16 + r for row r.  A pixel's test is then `(mask & my two bits) == my two bits` -- two
+    // instructions instead of film_weight's fourteen (four ceil / floor, four conversions, four comparisons ...) per (sample, pixel) pair.
+    __shared__ uint32_t s_m[400];
     tab[threadIdx.x] = table[threadIdx.x];
     const int32_t tx0 = (int32_t)(blockIdx.x % (uint32_t)tiles_x) * 16, ty0 = y0 + (int32_t)(blockIdx.x / (uint32_t)tiles_x) * 16;
     const int32_t lx = (int32_t)(threadIdx.x & 15u), ly = (int32_t)(threadIdx.x >> 4);
     const int32_t x = tx0 + lx, y = ty0 + ly;
     const bool live = x < R.W && y < y1;
+    const uint32_t my_bits = (1u << (uint32_t)lx) | (1u << (16u + (uint32_t)ly));
     v4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
     if (live) acc = film[(size_t)y * (size_t)R.W + (size_t)x];
     const uint32_t npix = (uint32_t)(R.row1 - R.row0) * (uint32_t)R.NX;
@@ -953,16 +958,23 @@ __global__ __launch_bounds__(BLOCK) void k_film(DParams R, DSampler S, DPaths P,
                 const f2a pf = pslot(P.pfilm, pid); const v4 Lv = pslot(P.L, pid);
                 pfx = pf.x; pfy = pf.y; lr = Lv.x; lg = Lv.y; lb = Lv.z;
             }
-            v4 a; a.x = pfx; a.y = pfy; a.z = lr; a.w = lg; s_a[e] = a; s_lb[e] = lb;
+            const float pdx = pfx - 0.5f, pdy = pfy - 0.5f; // film_weight's own first steps on the same values
+            const int32_t p0x = (int32_t)ceil_(pdx - 2.0f), p0y = (int32_t)ceil_(pdy - 2.0f), p1x = (int32_t)(floor_(pdx + 2.0f) + 1.0f), p1y = (int32_t)(floor_(pdy + 2.0f) + 1.0f);
+            auto span = [](int32_t lo, int32_t hi) { // bits [lo, hi) of a 16-bit field, both ends clipped to it
+                const uint32_t l = (uint32_t)(lo < 0 ? 0 : (lo > 16 ? 16 : lo)), h = (uint32_t)(hi < 0 ? 0 : (hi > 16 ? 16 : hi));
+                return h > l ? ((1u << h) - 1u) & ~((1u << l) - 1u) : 0u;
+            };
+            s_m[e] = span(p0x - tx0, p1x - tx0) | (span(p0y - ty0, p1y - ty0) << 16);
+            v4 a; a.x = pdx; a.y = pdy; a.z = lr; a.w = lg; s_a[e] = a; s_lb[e] = lb;
         }
         __syncthreads();
         if (live) {
             for (int32_t dx = 0; dx < 5; ++dx)
                 for (int32_t dy = 0; dy < 5; ++dy) {
                     const int32_t e = (ly + dy) * 20 + (lx + dx);
-                    float w;
+                    if ((s_m[e] & my_bits) != my_bits) continue; // x < p0x || x >= p1x || y < p0y || y >= p1y
                     const v4 a = s_a[e];
-                    if (!film_weight(a.x, a.y, x, y, tab, w)) continue;
+                    const float w = film_weight_inside(a.x, a.y, x, y, tab);
                     acc.x += a.z * w; acc.y += a.w * w; acc.z += s_lb[e] * w; acc.w += w;
                 }
         }
