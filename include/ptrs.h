@@ -232,7 +232,7 @@ typedef struct PtrsScene PtrsScene;
 
 /* Process-wide tuning knobs; the library reads no environment variables.  Names: "lanes" (1-8 concurrent pipeline lanes;
  * 0 = four, one for a job under 4 M paths), "grid_mult" (queue segments -- one wave each -- per pass = CUs x 8 x grid_mult; 0 = 1
- * with several lanes, 8 with one), "grid_pct" (share of its resident capacity a persistent launch takes; 0 = 100, or 50 with several
+ * with several lanes -- up to 4 for scenes whose tree is traversed out of HBM / L2, by the paths of a pass --, 8 with one), "grid_pct" (share of its resident capacity a persistent launch takes; 0 = 100, or 50 with several
  * lanes and a grid_mult given by hand), "persist" (0/1), "whole_rounds" (0/1), "refill" / "refill_connect" (idle-lane threshold of the
  * lane-refill traversal kernels, 0 = refill only when the whole wave is idle, -1 = by scene), "vote" (phase voting in the traversal
  * kernels: 0 off, 1 on, 2 extension kernel only, -1 = by scene), "stack_lds" (8 or 16 LDS stack entries per lane), "shade_lds"

@@ -41,7 +41,7 @@ struct Options {
     int refill = -1;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend; -1 = by scene (32 with phase voting and no alpha masks, else 16)
     int refill_connect = -1;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
-    int grid_mult = 0;        // queue segments (one wave each) per pass: CUs x 8 x grid_mult; 0 = 1 with several lanes (2 048 on MI355X), 8 with one (16 384; Cornell single-lane frame at 4 / 8 / 16: 252 / 216 / 222 ms)
+    int grid_mult = 0;        // queue segments (one wave each) per pass: CUs x 8 x grid_mult; 0 = with several lanes 1 (2 048 on MI355X; 1-4 for scenes whose tree is in HBM, by the paths of a pass: HipBackend::lanes), 8 with one (16 384; Cornell single-lane frame at 4 / 8 / 16: 252 / 216 / 222 ms)
     int grid_pct = 0;         // share of its resident capacity a persistent launch takes: below 100 a kernel leaves wave slots to the kernels of the other pipeline lanes; 0 = 100 (50 with several lanes and a grid_mult given by hand)
     int whole_rounds = 0;     // 1: segments per pass rounded to a whole multiple of the traversal kernels' resident waves (HipBackend::whole_rounds); measured within noise of 0 (exactly CUs x 8 x grid_mult) on Cornell / classroom, 2.5 % slower on colonnade
     int persist = 1;          // queue kernels are launched with the workgroups that fit the machine at once (occupancy x CUs); 0: with 8 per CU, the hardware's maximum (A/B hook)
@@ -1158,7 +1158,19 @@ struct HipBackend {
         int want = opt.lanes;
         if (want == 0) want = job_paths >= (4ull << 20) ? 4 : 1;
         n_lanes = (uint32_t)(want < 1 ? 1 : (want > MAX_LANES ? MAX_LANES : want));
-        if (opt.grid_mult == 0) { opt.grid_mult = n_lanes > 1 ? 1 : 8; if (opt.grid_pct == 0) opt.grid_pct = 100; }
+        if (opt.grid_mult == 0) {
+            opt.grid_mult = n_lanes > 1 ? 1 : 8;
+            // Scenes whose tree lives in HBM / L2 (quad form) wait for node fetches and gain from more waves of a kernel in flight once a
+            // segment still holds ~10 k paths: classroom (66 M paths per pass) 801 -> 797 / 784 / 795 ms at 4 096 / 6 144 / 8 192 segments,
+            // colonnade (15 M per pass) 107.3 -> 110.2 / 112.9 / 115.9: it stays at 2 048.  (The LDS-resident Cornell, bound by what the
+            // SIMDs issue, loses 1 % at 4 096.)
+            if (n_lanes > 1 && ps->sc.n_nodes4 != 0) {
+                const uint64_t per_pass = job_paths / n_lanes, per_unit = (uint64_t)ps->n_cu * 8u * 10240u;
+                const uint64_t k = (per_pass + per_unit / 2) / per_unit;
+                opt.grid_mult = (int)(k < 1 ? 1 : (k > 4 ? 4 : k));
+            }
+            if (opt.grid_pct == 0) opt.grid_pct = 100;
+        }
         if (opt.grid_pct == 0) opt.grid_pct = n_lanes > 1 ? 50 : 100; // (several lanes with many segments each: a launch takes half of its resident capacity)
         return n_lanes;
     }
