@@ -236,7 +236,7 @@ def test_launch_policy_options_do_not_change_the_film(ptrs):
     scenes_mod = __import__("importlib").import_module("pathtracer-rs_amd.scenes")
     cases = [(lambda: ptrs.import_scene(CORNELL, (96, 80)), 16, 8, 30000), (lambda: scenes_mod.material_zoo((72, 48)), 8, 15, 20000)]
     combos = [{}, {"lanes": 1}, {"lanes": 4, "grid_pct": 10}, {"grid_mult": 1, "persist": 0}, {"grid_mult": 64, "whole_rounds": 1}, {"lanes": 3, "grid_pct": 100, "grid_mult": 3},
-              {"lanes": 2, "fused_epilogue": 0, "grid_mult": 2}]
+              {"lanes": 2, "fused_epilogue": 0, "grid_mult": 2}, {"lanes": 4, "node_form": 2}, {"lanes": 4, "node_form": 2, "grid_mult": 3}]  # (node_form 2: quad nodes with per-axis planes out of global memory)
     for scene_fn, spp, depth, ppp in cases:
         ref, st0 = film(scene_fn, combos[0], spp, depth, ppp)
         assert st0.passes >= 2 and st0.queue_segments > 0 and st0.lanes >= 1
