@@ -2,7 +2,10 @@
 """bench.py -- headline benchmark of the render() hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: one process per GPU over RCCL.  Started under a launcher (python -m torch.distributed.run --nproc-per-node N ...
+    bench.py --gpus N ..., RANK / WORLD_SIZE in the environment) it is one of the N ranks; started plainly it launches the N
+    ranks ITSELF (self_launch: a child `python -m torch.distributed.run` before this process has imported torch or touched a
+    GPU), relays rank 0's JSON line and exits with the child's code.
 
 Workload (BASELINE.json configs[1]): data/cornell-box.xml, 1024x1024, 256 spp, max depth 15, Sobol sampler,
 Lambertian + area light.  One *step* = one complete PathIntegrator::render of that frame with the film accumulators
@@ -251,6 +254,92 @@ def collective_smoke():
         return {"ran": False, "ok": False, "detail": repr(e)}
 
 
+def self_launch(argv, n):
+    """`bench.py --gpus N` (N > 1) started without a launcher: this process -- which has not imported torch and will never touch a
+    GPU -- starts `python -m torch.distributed.run` with N ranks of this script as a CHILD process (never an exec), relays what
+    the ranks print (rank 0's JSON line) and returns the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env["PTRS_BENCH_LAUNCHED_BY"] = "bench.py self_launch"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %d ranks: %s" % (n, n, " ".join(cmd)), file=sys.stderr)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in p.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
+def init_dist(torch, dist, dev, want):
+    """Process group of a multi-rank run.  "nccl" is RCCL on ROCm; if it cannot be brought up (or fails its first all-reduce) the run
+    stays measurable over gloo with host staging, and says so.  Returns the backend that actually runs."""
+    import datetime
+    tmo = datetime.timedelta(seconds=int(os.environ.get("PTRS_DIST_TIMEOUT_S", "300")))  # a collective that hangs ends the run instead of the driver's budget
+    if want == "nccl":
+        try:
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)  # fail here, not in the timed region, if RCCL cannot be brought up
+            torch.cuda.synchronize()
+            return "nccl"
+        except Exception as e:
+            print("warning: RCCL initialisation failed (%r); falling back to gloo with host staging" % (e,), file=sys.stderr)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            want = "gloo"
+    dist.init_process_group(want, timeout=tmo)
+    return want
+
+
+def rehearse_main(args, rank, world, launched_by):
+    """--rehearse: the multi-rank plumbing of this script WITHOUT a render (the library has no CPU path, so a GPU-less box can
+    run this and nothing else): launcher -> ranks -> process group -> band plan -> the default film gather -> one JSON line
+    from rank 0.  Every rank fills its band of a small film with a pattern; rank 0 checks the gathered film.  No metric."""
+    import torch
+    import torch.distributed as dist
+    par = importlib.import_module("pathtracer-rs_amd.parallel")
+    backend = os.environ.get("PTRS_DIST_BACKEND", "gloo")
+    use_cuda = backend == "nccl" and torch.cuda.is_available()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(dev)
+    if world > 1:
+        backend = init_dist(torch, dist, dev, backend) if use_cuda else (dist.init_process_group(backend) or backend)
+    H, W = 96, 8
+    cost = [1.0 + (3.0 if 20 <= y < 40 else 0.0) for y in range(H)]  # uneven rows: the planned bands differ in height
+    bounds = par.plan_bands(H, world, cost) if world > 1 else [0, H]
+    want = torch.arange(H * W * 4, dtype=torch.float32).reshape(H, W, 4)
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    film[bounds[rank]:bounds[rank + 1]] = want[bounds[rank]:bounds[rank + 1]].to(dev)
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 1)):
+        par.gather_film_rows(film, H, rank, world, bounds=bounds)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.equal(film.cpu(), want)) if rank == 0 else True
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal of the multi-rank path (no render, no rays)", "value": None, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "pattern", "rehearsal": True,
+                          "config": {"workload": "none: band plan + film gather only", "row_bands": world, "band_plan": bounds,
+                                     "dist": {"backend": "rccl" if backend == "nccl" else backend, "world_size": dist.get_world_size() if world > 1 else 1, "launched_by": launched_by}},
+                          "gathered_film_ok": ok}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 TRACE_WORKLOADS = {"trace-colonnade": ("colonnade", (1280, 720)), "trace-classroom": ("classroom", (1920, 1080))}
 
 
@@ -341,6 +430,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collective-smoke", action="store_true", help="N = 1: skip the child process that brings up RCCL at world size 1 and runs the film gather")
     ap.add_argument("--even-bands", action="store_true", help="N > 1: bands of equal height instead of equal cost")
+    ap.add_argument("--rehearse", action="store_true", help="the multi-rank plumbing only (launch, process group, band plan, film gather), no render: runs without a GPU over gloo")
     ap.add_argument("--profile", action="store_true", help="for rocprofv3 runs: render exactly --steps frames on ONE pipeline lane (no counter / warm-up frames, no JSON)")
     ap.add_argument("--rays", default="", help="trace workloads: an .npz of ray sets; written (and nothing else done) when it does not exist, read instead of rendering when it does")
     ap.add_argument("--node-order", type=int, default=-1, help="trace workloads: quad-node order behind the LDS-cached top (0 depth-first, 1 treelets)")
@@ -349,14 +439,19 @@ def main():
     args = ap.parse_args()
     if args.workload in TRACE_WORKLOADS:
         return trace_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher around us: be the launcher (before torch is imported, before any GPU call)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched_by = os.environ.get("PTRS_BENCH_LAUNCHED_BY", "external launcher (RANK / WORLD_SIZE in the environment)" if world > 1 else "single process")
+    if args.rehearse:
+        sys.exit(rehearse_main(args, rank, world, launched_by))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks on one GPU
@@ -364,22 +459,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     backend = os.environ.get("PTRS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals that share a GPU
     if world > 1:
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)  # fail here, not in the timed region, if RCCL cannot be brought up
-                torch.cuda.synchronize()
-            except Exception as e:  # keep the run measurable: CPU-staged gather over gloo, flagged in the JSON
-                print("warning: RCCL initialisation failed (%r); falling back to gloo with host staging" % (e,), file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
+        backend = init_dist(torch, dist, dev, backend)
 
     pkg = importlib.import_module("pathtracer-rs_amd")
     par = importlib.import_module("pathtracer-rs_amd.parallel")
@@ -407,16 +487,36 @@ def main():
         row_b, row_e = par.band_for_rank(H, rank, world)
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    gather_mode, preflight = "p2p", None
+    if world > 1:
+        # The exact gather of the timed region (default mode, this run's band plan) once on a small film BEFORE anything is timed: the
+        # first multi-GPU run meets the point-to-point batch here; if it raises, the padded dist.gather takes over and the line says so.
+        small = torch.full((H, 4, 4), float(rank), dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+        try:
+            par.gather_film_rows(small, H, rank, world, bounds=bounds)
+            if backend == "nccl":
+                torch.cuda.synchronize()
+            if rank == 0:
+                bb = bounds if bounds is not None else [par.band_for_rank(H, r, world)[0] for r in range(world)] + [H]
+                assert all(bool((small[bb[r]:bb[r + 1]] == float(r)).all()) for r in range(world)), "gathered rows differ"
+            preflight = "p2p ok"
+        except Exception as e:  # (a hang instead ends at PTRS_DIST_TIMEOUT_S)
+            preflight = "p2p failed: %r; using the padded gather" % (e,)
+            gather_mode = "gather"
+        flag = torch.tensor([1.0 if gather_mode == "gather" else 0.0], device=small.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # all ranks take the same branch
+        if float(flag[0]) > 0:
+            gather_mode = "gather"
 
     def step(flags):
         film.zero_()
         st = integ.render_device(cam, scene, film.data_ptr(), stream=stream, row_begin=row_b, row_end=row_e, flags=flags)
         if world > 1:
             if backend == "nccl":
-                par.gather_film_rows(film, H, rank, world, bounds=bounds)
+                par.gather_film_rows(film, H, rank, world, bounds=bounds, mode=gather_mode)
             else:  # CPU-staged gather (rehearsal only)
                 host = film.cpu()
-                par.gather_film_rows(host, H, rank, world, bounds=bounds)
+                par.gather_film_rows(host, H, rank, world, bounds=bounds, mode=gather_mode)
                 if rank == 0:
                     film.copy_(host)
         return st
@@ -489,7 +589,7 @@ def main():
         roof = {
             "kernel": "%s kernels (%s)" % (dom, ", ".join(d["counters"]["kernels"]) if d.get("counters") else ("k_extend_rf + k_connect_rf" if dom == "traversal" else "k_shade<material, features>")),
             "bound": d.get("bound"),
-            "why": "neither class moves more than a fraction of the HBM peak (hbm.frac); the scarce resource is vector issue: `frac` is the share of the SIMDs' vector-ALU time the class's instructions need at the measured gfx950 issue rates (valu_ceiling), the rest of a wave's time is s_waitcnt (wave_wait_frac) with too few resident waves to cover it",
+            "why": "neither class moves more than a fraction of the HBM peak (hbm.frac); the scarce resource is vector issue: `frac` is the share of the SIMDs' vector-ALU time the class's instructions need at the measured gfx950 issue rates (valu_ceiling), the rest of a wave's time is s_waitcnt (wave_wait_frac) -- dependent chains inside a wave (LDS reads -> slab test -> stack) that more resident waves did NOT shorten (DESIGN 4.1)",
             "achieved": d.get("valu_ginst_per_s"), "peak": d.get("valu_ceiling_ginst_per_s"), "unit": "G wave64 VALU instructions/s (peak = what 1024 SIMDs issue of this class's instruction mix at the measured rates)",
             "frac": d.get("valu_pipe_frac"), "frac_lo_hi": d.get("valu_pipe_frac_lo_hi"),
             "wave": {"issue": d.get("wave_issue_frac"), "wait": d.get("wave_wait_frac"), "stall": d.get("wave_stall_frac"), "salu_per_valu": d.get("salu_per_valu"), "lanes_per_valu_inst": d.get("lanes_per_valu_inst"),
@@ -528,6 +628,9 @@ def main():
                        "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world,
                        "band_plan": ("single band" if world == 1 else ("equal height" if bounds is None else "equal cost (1-spp probe in 64 strips): rows %s" % (bounds,))),
                        "band_probe_ms": probe_ms, "value_incl_band_probe": rays / (dt + args.steps * probe_ms * 1e-3) / 1e6,  # a host that plans its bands per frame pays the probe per frame
+                       "dist": {"backend": ("none" if world == 1 else ("rccl" if backend == "nccl" else backend + " (fallback or rehearsal: NOT an RCCL number)")), "world_size": dist.get_world_size() if world > 1 else 1,
+                                "launched_by": launched_by, "gather_mode": gather_mode if world > 1 else None, "gather_preflight": preflight,
+                                "note": "no N > 1 hardware run existed when this was written: the first one is the first execution of the RCCL gather at world size > 1"},
                        "collective": ("none" if world == 1 else ("rccl gather of film row bands" if backend == "nccl" else backend + " gather (host-staged fallback, NOT an RCCL number)")),
                        "halo_overhead": rows_traced / float(H + 4) - 1.0, "rays_traced_incl_halo_per_step": rays_traced / args.steps,
                        "rays_by_kind_rank0_per_step": {"extension (closest hit; one per path vertex reached)": int(st.rays_extension), "shadow (any hit)": int(st.rays_shadow), "mis (closest hit)": int(st.rays_mis)},

@@ -52,11 +52,18 @@ def probe_row_cost(pkg, camera, scene, max_depth, device=0, strips=64, spp=1):
     return cost
 
 
+_P2P_READY = set()  # process groups on which a collective has run before the first point-to-point batch (see gather_film_rows)
+
+
 def gather_film_rows(film, height, rank, world, group=None, dst=0, bounds=None, mode="p2p", force=False):
     """film: (H, W, 4) tensor whose rows of this rank's band are valid (band_for_rank, or bounds[rank]:bounds[rank + 1] when
-    a plan is given).  After the call rank `dst` holds the complete film.
+    a plan is given).  After the call rank `dst` holds the complete film.  `rank`, `world` and `dst` are ranks of `group`
+    (the default group when None).
     mode "p2p" (default): every other rank sends exactly its band, `dst` receives each band straight into its rows of the
-    film (one batch_isend_irecv: no padding, no staging copy -- bands of a cost-weighted plan differ in height).
+    film (one batch_isend_irecv: no padding, no staging copy -- bands of a cost-weighted plan differ in height).  Ranks
+    with an empty band take no part in the batch, which RCCL only tolerates on a communicator that exists already: the
+    first p2p call on a group therefore runs one dist.barrier(group) first (every rank of the group makes the same call,
+    so every rank reaches it).  Peers are addressed by their GLOBAL rank (P2POp's convention), translated from the group's.
     mode "gather": one dist.gather of equal-size slabs, bands padded to the largest one (the round-2 form; also what
     `bench.py`'s world-size-1 collective smoke runs with force=True, where there is no peer to send to)."""
     if world == 1 and not force:
@@ -64,18 +71,24 @@ def gather_film_rows(film, height, rank, world, group=None, dst=0, bounds=None, 
     band = (lambda r: (int(bounds[r]), int(bounds[r + 1]))) if bounds is not None else (lambda r: band_for_rank(height, r, world))
     b, e = band(rank)
     if mode == "p2p" and world > 1:
+        key = id(group) if group is not None else None
+        if key not in _P2P_READY:
+            dist.barrier(group)
+            _P2P_READY.add(key)
+        peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
         ops = []
         if rank == dst:
             for r in range(world):
                 rb, re = band(r)
                 if r != dst and re > rb:
-                    ops.append(dist.P2POp(dist.irecv, film[rb:re], r, group))  # a contiguous slab of rows: received in place
+                    ops.append(dist.P2POp(dist.irecv, film[rb:re], peer(r), group))  # a contiguous slab of rows: received in place
         elif e > b:
-            ops.append(dist.P2POp(dist.isend, film[b:e].contiguous(), dst, group))
+            ops.append(dist.P2POp(dist.isend, film[b:e].contiguous(), peer(dst), group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return film
+    gdst = dist.get_global_rank(group, dst) if group is not None else dst  # dist.gather's `dst` is a global rank as well
     max_rows = max(band(r)[1] - band(r)[0] for r in range(world))
     if e - b == max_rows:
         send = film[b:e]
@@ -85,12 +98,12 @@ def gather_film_rows(film, height, rank, world, group=None, dst=0, bounds=None, 
     send = send.contiguous()
     if rank == dst:
         bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, bufs, dst=dst, group=group)
+        dist.gather(send, bufs, dst=gdst, group=group)
         for r in range(world):
             if r == dst:
                 continue
             rb, re = band(r)
             film[rb:re] = bufs[r][: re - rb]
     else:
-        dist.gather(send, None, dst=dst, group=group)
+        dist.gather(send, None, dst=gdst, group=group)
     return film

@@ -105,3 +105,30 @@ def test_plan_bands_equal_cost():
     per = np.array([cost[b[i]:b[i + 1]].sum() for i in range(world)])
     even = np.array([cost[h * i // world:h * (i + 1) // world].sum() for i in range(world)])
     assert per.max() / per.mean() < 1.25 < even.max() / even.mean()
+
+
+def _subgroup_worker(rank, world, port, mode):
+    sys.path.insert(0, ROOT)
+    import importlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module("pathtracer-rs_amd.parallel")
+    grp = dist.new_group([1, 2])  # group ranks 0, 1 = global ranks 1, 2
+    if rank in (1, 2):
+        g_rank = rank - 1
+        want = torch.arange(20 * 4 * 4, dtype=torch.float32).reshape(20, 4, 4)
+        bounds = [0, 7, 20]
+        film = torch.zeros_like(want)
+        film[bounds[g_rank]:bounds[g_rank + 1]] = want[bounds[g_rank]:bounds[g_rank + 1]]
+        par.gather_film_rows(film, 20, g_rank, 2, group=grp, dst=0, bounds=bounds, mode=mode)
+        if g_rank == 0:
+            assert torch.equal(film, want)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["p2p", "gather"])
+def test_gather_on_a_subgroup_uses_group_ranks(mode):
+    """rank / world / dst are ranks of `group`; the peers of the point-to-point batch (and dist.gather's dst) are global ranks"""
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), mode), nprocs=3, join=True)
