@@ -109,10 +109,13 @@ def test_band_and_pass_decomposition_is_exact(ptrs, orc):
     assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), film_full["weight"].view(np.uint32))
 
 
-def _gpu_vs_oracle(ptrs, orc, cam, scene, spp, depth):
+def _gpu_vs_oracle(ptrs, orc, cam, scene, spp, depth, **opts):
     integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(spp, cam.film.get_sample_bounds()), depth)
-    samples = integ.render(cam, scene, want_samples=True)
+    with ptrs.options(**opts):
+        samples = integ.render(cam, scene, want_samples=True)
     st = integ.last_stats
+    if "lanes" in opts:
+        assert st.lanes == opts["lanes"]
     film_ref, ref, ost = orc.OracleScene(scene).render(cam, orc.make_params(cam.film.width, cam.film.height, spp, depth), n_threads=8, want_samples=True)
     assert (st.samples, st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.samples, ost.rays_extension, ost.rays_shadow, ost.rays_mis)
     bad = (samples.view(np.uint32) != ref.view(np.uint32)).any(axis=-1)
@@ -125,6 +128,18 @@ def test_material_zoo_matches_oracle(ptrs, orc, scenes):
     point + directional + area lights: every per-sample radiance bit-identical to the oracle."""
     cam, scene = scenes.material_zoo((120, 80))
     _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15)
+
+
+def test_shipped_four_lane_schedule_matches_oracle(ptrs, orc, scenes):
+    """Jobs under 4 M paths run on ONE pipeline lane with 16 384 segments; a full frame runs on FOUR lanes with 2 048 segments per pass
+    (HipBackend::lanes).  Here the four-lane schedule itself is held against the oracle, sample by sample: the LDS-form scene
+    (Cornell) and a quad-form scene (colonnade, tree in HBM), and the fused tail kernel of thin rounds with it."""
+    cam, scene = ptrs.import_scene(CORNELL, (64, 64))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15, lanes=4)
+    cam, scene = scenes.colonnade((160, 90))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15, lanes=4)
+    cam, scene = scenes.material_zoo((120, 80))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15, lanes=4)
 
 
 def test_triangle_soup_matches_oracle(ptrs, orc, scenes):
@@ -552,15 +567,17 @@ def test_sobol_dimension_overrun_is_an_error(ptrs):
 
 
 def test_cfg2_band_at_full_settings(ptrs, orc):
-    """BASELINE configs[1] exactly (Cornell 1024x1024, 256 spp, depth 15) on a 4-row band: ray counts identical to the
-    oracle's over 2.1 M paths, film rows within the tolerance of two summation orders."""
+    """BASELINE configs[1] exactly (Cornell 1024x1024, 256 spp, depth 15) on a 16-row band = 5.3 M paths: above the 4 M-path
+    threshold, so this is the SHIPPED schedule (four pipeline lanes, 2 048 segments per pass) against the oracle directly: ray
+    counts identical, film rows within the tolerance of two summation orders."""
     cam, scene = ptrs.import_scene(CORNELL, (1024, 1024))
     integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(256, cam.film.get_sample_bounds()), 15)
-    rb, re = 510, 514
+    rb, re = 504, 520
     integ.render(cam, scene, row_begin=rb, row_end=re)
     st = integ.last_stats
+    assert st.lanes == 4 and st.queue_segments == 2048 and st.passes >= 4
     film_ref, _, ost = orc.OracleScene(scene).render(cam, orc.make_params(1024, 1024, 256, 15, row_begin=rb, row_end=re), n_threads=16)
-    assert st.samples == ost.samples == 1028 * 8 * 256
+    assert st.samples == ost.samples == 1028 * 20 * 256
     assert (st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.rays_extension, ost.rays_shadow, ost.rays_mis)
     a, b = cam.film.pixels[rb:re], film_ref[rb:re]
     assert np.allclose(a["weight"], b["weight"], rtol=1e-4) and rel_l2(a["rgb"] / a["weight"][..., None], b["rgb"] / b["weight"][..., None]) < 1e-4
