@@ -68,7 +68,49 @@ PT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 PT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 PT_HD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+// f3 / float: three quotients by ONE divisor.  hipcc expands every IEEE binary32 division into eleven instructions,
+//     s = v_div_scale(b, b, a); n = v_div_scale(a, b, a); r0 = v_rcp(s); e = fma(-s, r0, 1); r = fma(e, r0, r0);
+//     q0 = n * r; m0 = fma(-s, q0, n); q1 = fma(m0, r, q0); m1 = fma(-s, q1, n); q = v_div_fmas(m1, r, q1); v_div_fixup(q, b, a)
+// (46 cycles of a SIMD apiece, profiles/r03_valu_ceiling.json).  v_div_scale returns its operand unchanged (and VCC = 0, which makes
+// v_div_fmas a plain fma) unless an exponent is extreme -- the divisor denormal or >= 2^126, the numerator below 2^-103, the
+// quotient's exponent beyond +-96 / into the denormals -- and v_div_fixup returns its first operand unless an operand is zero,
+// infinite or a NaN or the quotient over- / underflows.  So with |b| and every non-zero |a| in [2^-47, 2^48) (quotients in
+// (2^-95, 2^95)) the expansion IS the plain chain below, whose first three instructions depend on the divisor alone: computed once,
+// 3 + 3 x 5 instructions of the fast class instead of 3 x 11 with twelve slow ones.  Numerators that are zero stay on the fast path:
+// the chain is run on -|b| (its values are then the exact negatives of the expansion's, rounding to nearest is symmetric) because
+// with a negative divisor the signs of zero come out as IEEE's (a ^ b) for all four sign combinations -- with a positive one
+// -0 / b would come back as +0 (x + (-x) = +0) -- and the quotients' sign bits are flipped afterwards where b was positive.
+// Everything else (infinities, NaNs, denormals, extreme exponents) takes the compiler's division.  Identity on bits:
+// ptrs_selftest_div3 compares it with `/` over 2^34 random, edge-case and render-range operand sets (tests/test_gpu_kat.py).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PTRS_NO_DIV3) // (PTRS_NO_DIV3: A/B builds, tools/ablate.sh)
+PT_HD uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+PT_HD uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+PT_HD f3 operator/(f3 a, float s) {
+    const uint32_t LO = 80u << 23, HI = 175u << 23; // biased exponents 80 .. 174: [2^-47, 2^48)
+    const uint32_t bx = ptf_bits(a.x), by = ptf_bits(a.y), bz = ptf_bits(a.z), bs = ptf_bits(s);
+    const uint32_t ux = bx & 0x7fffffffu, uy = by & 0x7fffffffu, uz = bz & 0x7fffffffu, us = bs & 0x7fffffffu;
+    const uint32_t lo = umin_(umin_(ux - 1u, uy - 1u), uz - 1u); // v_min3_u32; a zero numerator wraps to the top and passes
+    const uint32_t hi = umax_(umax_(ux, uy), uz);                // v_max3_u32; infinities and NaNs fail
+    if (us - LO < HI - LO && lo >= LO - 1u && hi < HI) { // divisor in [LO, HI); numerators 0 or in [LO, HI)
+        const float nb = ptf_from_bits(us | 0x80000000u); // -|b|
+        const float r0 = __builtin_amdgcn_rcpf(nb);
+        const float e = __builtin_fmaf(-nb, r0, 1.0f);
+        const float r = __builtin_fmaf(e, r0, r0);
+        const uint32_t flip = ~bs & 0x80000000u; // b > 0: the quotients by -|b| have the wrong sign
+        float q[3] = {a.x, a.y, a.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float n = q[k];
+            const float q0 = n * r, m0 = __builtin_fmaf(-nb, q0, n), q1 = __builtin_fmaf(m0, r, q0), m1 = __builtin_fmaf(-nb, q1, n);
+            q[k] = ptf_from_bits(ptf_bits(__builtin_fmaf(m1, r, q1)) ^ flip);
+        }
+        return mk3(q[0], q[1], q[2]);
+    }
+    return mk3(a.x / s, a.y / s, a.z / s);
+}
+#else
 PT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+#endif
 PT_HD f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
 PT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }

@@ -1029,6 +1029,63 @@ __global__ __launch_bounds__(BLOCK) void k_sobol(DSampler S, uint32_t n, const i
     out[i] = sample_dimension(S, idx, dims[i], pixel_scramble(px[i], py[i]), px[i], py[i]);
 }
 
+// Self-test of the shared-divisor division (pt_vec.h, operator/(f3, float)) against the compiler's IEEE division, bit for bit, on
+// operand sets drawn from a counter-based generator.  mode 0: raw random bit patterns (every class at its natural share: 1/256 each of
+// zeros + denormals and infinities + NaNs); 1: exponents around every threshold of the fast path's window and of v_div_scale /
+// v_div_fixup, mantissas random / all zeros / all ones, signed zeros; 2: the ranges of a render (pdf-like divisors 2^-27 .. 2^13,
+// radiance-like numerators, a quarter of them zero); 3: beta / (1 - q) of the Russian roulette; 4: quotients next to 1 and next to
+// rounding ties (a = b x small factors, a = b +- ulps).
+__device__ inline uint64_t mix64(uint64_t z) { z += 0x9e3779b97f4a7c15ull; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+__device__ inline uint32_t edge_bits(uint32_t r) { // r: 32 random bits
+    const uint32_t exps[32] = {0, 0, 1, 2, 22, 23, 24, 25, 31, 32, 33, 78, 79, 80, 81, 82, 126, 127, 128, 150, 172, 173, 174, 175, 176, 221, 222, 223, 252, 253, 254, 255};
+    const uint32_t e = exps[r & 31u], how = (r >> 5) & 3u, sign = (r >> 7) & 1u;
+    const uint32_t man = how == 0u ? 0u : (how == 1u ? 0x7fffffu : ((r >> 9) & 0x7fffffu));
+    return (sign << 31) | (e << 23) | man;
+}
+__global__ __launch_bounds__(BLOCK) void k_selftest_div3(uint64_t seed, uint32_t mode, uint64_t per_thread, unsigned long long *out /* [0] mismatches, [1] fast-path sets */, uint32_t *first_bad /* 10 words + a lock */) {
+    const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long bad = 0, fast = 0;
+    for (uint64_t k = 0; k < per_thread; ++k) {
+        const uint64_t h0 = mix64(seed ^ (tid * per_thread + k) * 0xd1342543de82ef95ull), h1 = mix64(h0);
+        uint32_t w[4] = {(uint32_t)h0, (uint32_t)(h0 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32)};
+        if (mode == 1u) { for (int j = 0; j < 4; ++j) w[j] = edge_bits(w[j]); }
+        else if (mode == 2u) {
+            w[3] = ((100u + (w[3] >> 24) % 41u) << 23) | (w[3] & 0x7fffffu);
+            for (int j = 0; j < 3; ++j) w[j] = (w[j] >> 30) == 0u ? (w[j] & 0x80000000u) : (((90u + (w[j] >> 24) % 51u) << 23) | (w[j] & 0x7fffffu) | ((w[j] >> 29) == 7u ? 0x80000000u : 0u));
+        } else if (mode == 3u) {
+            const float mx = (float)(w[3] >> 8) * 0x1p-24f;
+            const float q = max_nz(0.05f, 1.0f - mx);
+            w[3] = f2u(1.0f - q);
+            for (int j = 0; j < 3; ++j) w[j] = f2u((float)(w[j] >> 8) * 0x1p-23f * ((w[j] & 255u) == 0u ? 0.0f : 1.0f));
+        } else if (mode == 4u) {
+            const uint32_t b = ((80u + (w[3] >> 24) % 90u) << 23) | (w[3] & 0x7fffffu) | ((w[3] >> 23 & 1u) << 31);
+            w[3] = b;
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t sel = w[j] & 7u, d = (w[j] >> 3) & 15u;
+                const float fb = u2f(b);
+                float a = fb;
+                if (sel == 0u) a = u2f(b + d); else if (sel == 1u) a = u2f(b - d); else if (sel == 2u) a = fb * (float)(1u + d); else if (sel == 3u) a = fb * (1.0f + (float)d * 0x1p-23f);
+                else if (sel == 4u) a = fb * 0x1.fffffep-1f; else if (sel == 5u) a = fb * 0.5f + u2f((f2u(fb) & 0xff800000u) - (12u << 23)); else if (sel == 6u) a = u2f((b & 0xff800000u) | 0x7fffffu); else a = u2f(b & 0xff800000u);
+                w[j] = f2u(a);
+            }
+        }
+        const float ax = u2f(w[0]), ay = u2f(w[1]), az = u2f(w[2]), b = u2f(w[3]);
+        const f3 got = mk3(ax, ay, az) / b;
+        const float wx = ax / b, wy = ay / b, wz = az / b; // the compiler's IEEE division
+        { // (how many sets took the fast path: the test wants to know that it was exercised)
+            const uint32_t LO = 80u << 23, HI = 175u << 23, ux = w[0] & 0x7fffffffu, uy = w[1] & 0x7fffffffu, uz = w[2] & 0x7fffffffu, us = w[3] & 0x7fffffffu;
+            auto okn = [&](uint32_t u) { return u == 0u || (u >= LO && u < HI); };
+            if (us >= LO && us < HI && okn(ux) && okn(uy) && okn(uz)) ++fast;
+        }
+        if (f2u(got.x) != f2u(wx) || f2u(got.y) != f2u(wy) || f2u(got.z) != f2u(wz)) {
+            ++bad;
+            if (atomicCAS(first_bad + 10, 0u, 1u) == 0u) { first_bad[0] = w[0]; first_bad[1] = w[1]; first_bad[2] = w[2]; first_bad[3] = w[3]; first_bad[4] = f2u(got.x); first_bad[5] = f2u(got.y); first_bad[6] = f2u(got.z); first_bad[7] = f2u(wx); first_bad[8] = f2u(wy); first_bad[9] = f2u(wz); }
+        }
+    }
+    if (bad) atomicAdd(out, bad);
+    atomicAdd(out + 1, fast);
+}
+
 // ---- device buffers ---------------------------------------------------------------------------------
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -1956,6 +2013,34 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
         stats->queue_segments = G; stats->grid_wgs[0] = grid; stats->resident_wgs_per_cu[0] = be.last_per_cu[HipBackend::T_EXTEND];
         cleanup();
         if (e != hipSuccess) { g_err = std::string("ptrs_trace_bench: ") + hipGetErrorString(e); return PTRS_ERR_DEVICE; }
+        return PTRS_OK;
+    });
+}
+
+int ptrs_selftest_div3(int32_t device, uint32_t mode, uint64_t n_sets, uint64_t seed, uint64_t *mismatches_out, uint64_t *fast_path_sets_out, uint32_t *first_bad_out) {
+    return guarded([&]() -> int {
+        if (!mismatches_out || mode > 4u || n_sets == 0) { g_err = "bad self-test request"; return PTRS_ERR_INVALID; }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available (this library has no CPU fallback)"; return PTRS_ERR_DEVICE; }
+        if (device < 0 || device >= ndev) { g_err = "device ordinal out of range"; return PTRS_ERR_INVALID; }
+        HIPCHK(hipSetDevice(device));
+        DevBuf out, fb;
+        int rc;
+        if ((rc = out.ensure(16)) != PTRS_OK || (rc = fb.ensure(44)) != PTRS_OK) { out.release(); fb.release(); return rc; }
+        hipError_t e = hipMemset(out.p, 0, 16);
+        if (e == hipSuccess) e = hipMemset(fb.p, 0, 44);
+        const uint32_t grid = 256u * 16u;
+        const uint64_t threads = (uint64_t)grid * BLOCK, per_thread = (n_sets + threads - 1) / threads;
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_div3, dim3(grid), dim3(BLOCK), 0, nullptr, seed, mode, per_thread, (unsigned long long *)out.p, (uint32_t *)fb.p); e = hipDeviceSynchronize(); }
+        if (e == hipSuccess) e = hipGetLastError();
+        unsigned long long h[2] = {0, 0}; uint32_t hb[11] = {0};
+        if (e == hipSuccess) e = hipMemcpy(h, out.p, 16, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hb, fb.p, 44, hipMemcpyDeviceToHost);
+        out.release(); fb.release();
+        if (e != hipSuccess) { g_err = std::string("ptrs_selftest_div3: ") + hipGetErrorString(e); return PTRS_ERR_DEVICE; }
+        *mismatches_out = h[0];
+        if (fast_path_sets_out) *fast_path_sets_out = h[1];
+        if (first_bad_out) std::memcpy(first_bad_out, hb, 40);
         return PTRS_OK;
     });
 }

@@ -314,3 +314,14 @@ def sobol_samples(params, px, py, sample_nums, dims):
     _check(load_library().ptrs_sobol_samples(C.byref(params), px.shape[0], C.c_void_p(px.ctypes.data), C.c_void_p(py.ctypes.data), C.c_void_p(sn.ctypes.data),
                                              C.c_void_p(dm.ctypes.data), C.c_void_p(out.ctypes.data), C.c_void_p(idx.ctypes.data)))
     return out, idx
+
+
+def selftest_div3(mode, n_sets, seed=1, device=0):
+    """ptrs_selftest_div3: the device code's shared-divisor division against the compiler's IEEE division over ~n_sets generated operand
+    sets.  Returns (mismatches, sets that took the fast path, first mismatch as 10 uint32 words: a0 a1 a2 b | got x3 | want x3)."""
+    L = load_library()
+    L.ptrs_selftest_div3.argtypes = [C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
+    bad, fast = C.c_uint64(0), C.c_uint64(0)
+    first = np.zeros(10, dtype=np.uint32)
+    _check(L.ptrs_selftest_div3(int(device), int(mode), int(n_sets), int(seed), C.byref(bad), C.byref(fast), C.c_void_p(first.ctypes.data)))
+    return int(bad.value), int(fast.value), first

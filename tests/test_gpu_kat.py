@@ -155,3 +155,20 @@ def test_traversal_against_exhaustive_search(ptrs, orc, scenes):
     assert np.array_equal(hg["t"].view(np.uint32), hb["t"].view(np.uint32))
     occ, _ = ptrs.trace_rays(scene, rays, any_hit=True)
     assert np.array_equal(occ["prim"] >= 0, hb["prim"] >= 0)
+
+
+def test_shared_divisor_division_is_ieee_division(ptrs):
+    """csrc/pt_vec.h computes f3 / float with ONE reciprocal (the divisor-only part of hipcc's own division expansion, shared by the
+    three quotients) where every operand's exponent keeps v_div_scale / v_div_fixup inert, and with the compiler's division elsewhere.
+    The oracle divides component by component with IEEE `/`, so this must be an identity on bits: compared here with the compiler's
+    `/` over 2^34 operand sets -- random bit patterns (2^33: zeros, denormals, infinities and NaNs at 1/128 of the values each), edge
+    exponents and mantissas around every threshold, the pdf / radiance ranges of a render, the Russian-roulette divisor 1 - q, and
+    quotients next to 1 and to rounding ties -- and the fast path must have been the one exercised where it is meant to be."""
+    total = 0
+    for mode, n, min_fast in ((0, 1 << 33, 0.0), (1, 1 << 31, 0.005), (2, 1 << 31, 0.99), (3, 1 << 31, 0.5), (4, 1 << 32, 0.9)):
+        bad, fast, first = ptrs.selftest_div3(mode, n, seed=0x5eed + mode)
+        assert bad == 0, "mode %d: %d of %d sets differ; first: a = %s b = %08x got %s want %s" % (
+            mode, bad, n, ["%08x" % v for v in first[:3]], first[3], ["%08x" % v for v in first[4:7]], ["%08x" % v for v in first[7:10]])
+        assert fast >= min_fast * n, "mode %d: only %d of %d sets took the fast path" % (mode, fast, n)
+        total += n
+    assert total >= 1 << 34
