@@ -337,8 +337,9 @@ int ptrs_sobol_samples(const PtrsRenderParams *params, uint32_t n, const int32_t
                        const int32_t *py, const uint64_t *sample_nums, const uint32_t *dims,
                        float *out, uint64_t *index_out /* may be NULL */);
 
-/* Self-test of the device code's shared-divisor division (csrc/pt_vec.h: f3 / float computes one reciprocal for three quotients; the
- * reference divides component by component, e.g. integrator.rs:63-75, 453-497) against the compiler's IEEE division, bit for bit, over
+/* Self-test of the device code's shared-divisor division (csrc/pt_vec.h, div_shared3: one reciprocal for three quotients -- measured,
+ * slower than the compiler's division in the shade kernels and therefore NOT on the render path; the reference divides component by
+ * component, e.g. integrator.rs:63-75, 453-497) against the compiler's IEEE division, bit for bit, over
  * about n_sets generated operand sets (a0, a1, a2, b).  mode 0 random bit patterns, 1 exponent / mantissa edge cases, 2 render ranges,
  * 3 Russian-roulette ranges, 4 quotients next to 1 and to rounding ties.  first_bad_out (NULL or 10 words): a0 a1 a2 b, the three
  * quotients computed, the three expected. */

@@ -68,7 +68,9 @@ PT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 PT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 PT_HD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
-// f3 / float: three quotients by ONE divisor.  hipcc expands every IEEE binary32 division into eleven instructions,
+// Three quotients by ONE divisor (MEASURED AND NOT USED: the default operator/ below is the compiler's division; -DPTRS_DIV3 switches it
+// for A/B builds; ptrs_selftest_div3 keeps the function itself under test).  hipcc expands every IEEE binary32 division into eleven
+// instructions,
 //     s = v_div_scale(b, b, a); n = v_div_scale(a, b, a); r0 = v_rcp(s); e = fma(-s, r0, 1); r = fma(e, r0, r0);
 //     q0 = n * r; m0 = fma(-s, q0, n); q1 = fma(m0, r, q0); m1 = fma(-s, q1, n); q = v_div_fmas(m1, r, q1); v_div_fixup(q, b, a)
 // (46 cycles of a SIMD apiece, profiles/r03_valu_ceiling.json).  v_div_scale returns its operand unchanged (and VCC = 0, which makes
@@ -80,12 +82,14 @@ PT_HD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
 // the chain is run on -|b| (its values are then the exact negatives of the expansion's, rounding to nearest is symmetric) because
 // with a negative divisor the signs of zero come out as IEEE's (a ^ b) for all four sign combinations -- with a positive one
 // -0 / b would come back as +0 (x + (-x) = +0) -- and the quotients' sign bits are flipped afterwards where b was positive.
-// Everything else (infinities, NaNs, denormals, extreme exponents) takes the compiler's division.  Identity on bits:
-// ptrs_selftest_div3 compares it with `/` over 2^34 random, edge-case and render-range operand sets (tests/test_gpu_kat.py).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PTRS_NO_DIV3) // (PTRS_NO_DIV3: A/B builds, tools/ablate.sh)
+// Everything else (infinities, NaNs, denormals, extreme exponents) takes the compiler's division.  Identity on bits: 0 mismatches in
+// 2^34 random, edge-case and render-range operand sets (tests/test_gpu_kat.py).  What it costs: the window test is 7 plain + 5
+// comparison-class vector instructions and, as a divergent branch, 11 scalar ones (a SIMD issues one scalar instruction per ~4
+// cycles): Cornell's Matte shade kernel 66.4 -> 69.3 ms, classroom's Disney kernels 278 -> 310 ms (ABAB).
+#if defined(__HIP_DEVICE_COMPILE__)
 PT_HD uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
 PT_HD uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
-PT_HD f3 operator/(f3 a, float s) {
+PT_HD f3 div_shared3(f3 a, float s) {
     const uint32_t LO = 80u << 23, HI = 175u << 23; // biased exponents 80 .. 174: [2^-47, 2^48)
     const uint32_t bx = ptf_bits(a.x), by = ptf_bits(a.y), bz = ptf_bits(a.z), bs = ptf_bits(s);
     const uint32_t ux = bx & 0x7fffffffu, uy = by & 0x7fffffffu, uz = bz & 0x7fffffffu, us = bs & 0x7fffffffu;
@@ -108,6 +112,11 @@ PT_HD f3 operator/(f3 a, float s) {
     }
     return mk3(a.x / s, a.y / s, a.z / s);
 }
+#else
+PT_HD f3 div_shared3(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PTRS_DIV3)
+PT_HD f3 operator/(f3 a, float s) { return div_shared3(a, s); }
 #else
 PT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 #endif

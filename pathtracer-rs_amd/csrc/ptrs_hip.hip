@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(BLOCK) void k_sobol(DSampler S, uint32_t n, const i
     out[i] = sample_dimension(S, idx, dims[i], pixel_scramble(px[i], py[i]), px[i], py[i]);
 }
 
-// Self-test of the shared-divisor division (pt_vec.h, operator/(f3, float)) against the compiler's IEEE division, bit for bit, on
+// Self-test of the shared-divisor division (pt_vec.h, div_shared3) against the compiler's IEEE division, bit for bit, on
 // operand sets drawn from a counter-based generator.  mode 0: raw random bit patterns (every class at its natural share: 1/256 each of
 // zeros + denormals and infinities + NaNs); 1: exponents around every threshold of the fast path's window and of v_div_scale /
 // v_div_fixup, mantissas random / all zeros / all ones, signed zeros; 2: the ranges of a render (pdf-like divisors 2^-27 .. 2^13,
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_div3(uint64_t seed, uint32_t
             }
         }
         const float ax = u2f(w[0]), ay = u2f(w[1]), az = u2f(w[2]), b = u2f(w[3]);
-        const f3 got = mk3(ax, ay, az) / b;
+        const f3 got = div_shared3(mk3(ax, ay, az), b);
         const float wx = ax / b, wy = ay / b, wz = az / b; // the compiler's IEEE division
         { // (how many sets took the fast path: the test wants to know that it was exercised)
             const uint32_t LO = 80u << 23, HI = 175u << 23, ux = w[0] & 0x7fffffffu, uy = w[1] & 0x7fffffffu, uz = w[2] & 0x7fffffffu, us = w[3] & 0x7fffffffu;

@@ -158,12 +158,12 @@ def test_traversal_against_exhaustive_search(ptrs, orc, scenes):
 
 
 def test_shared_divisor_division_is_ieee_division(ptrs):
-    """csrc/pt_vec.h computes f3 / float with ONE reciprocal (the divisor-only part of hipcc's own division expansion, shared by the
-    three quotients) where every operand's exponent keeps v_div_scale / v_div_fixup inert, and with the compiler's division elsewhere.
-    The oracle divides component by component with IEEE `/`, so this must be an identity on bits: compared here with the compiler's
-    `/` over 2^34 operand sets -- random bit patterns (2^33: zeros, denormals, infinities and NaNs at 1/128 of the values each), edge
-    exponents and mantissas around every threshold, the pdf / radiance ranges of a render, the Russian-roulette divisor 1 - q, and
-    quotients next to 1 and to rounding ties -- and the fast path must have been the one exercised where it is meant to be."""
+    """csrc/pt_vec.h, div_shared3: f3 / float with ONE reciprocal (the divisor-only part of hipcc's own division expansion, shared by the
+    three quotients) where every operand's exponent keeps v_div_scale / v_div_fixup inert, the compiler's division elsewhere.  It is an
+    identity on bits -- compared here with the compiler's `/` over 2^34 operand sets: random bit patterns (2^33: zeros, denormals,
+    infinities and NaNs at 1/128 of the values each), edge exponents and mantissas around every threshold, the pdf / radiance ranges
+    of a render, the Russian-roulette divisor 1 - q, quotients next to 1 and to rounding ties -- but its window test costs more than it
+    saves, so the render path keeps the compiler's division; the function stays under test as a measured building block."""
     total = 0
     for mode, n, min_fast in ((0, 1 << 33, 0.0), (1, 1 << 31, 0.005), (2, 1 << 31, 0.99), (3, 1 << 31, 0.5), (4, 1 << 32, 0.9)):
         bad, fast, first = ptrs.selftest_div3(mode, n, seed=0x5eed + mode)
