@@ -54,7 +54,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E peak
 SIMDS, CUS = 1024.0, 256.0
 CLASS_B_CYCLES = 4.2                       # profiles/r03_valu_ceiling.json: one comparison / select / min-max class instruction per 4.2 cycles and SIMD; fp32 add / mul / fma issue beside them
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_%s.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_%s.json")
 CEILING_FILE = os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_%s_rows.npz")
 
@@ -371,7 +371,7 @@ def trace_main(args):
         st, _ = pkg.trace_bench(scene, sets["secondary rays (round 3)"], repeats=args.steps)
         print("profile: %d launches of %d secondary rays" % (args.steps + 1, len(sets["secondary rays (round 3)"])))
         return
-    src_hash = importlib.import_module("pathtracer-rs_amd.build").source_hash()
+    src_hash = pkg.build_id()  # the id the LOADED library was built with (sources + every compiler flag)
     pmc_path = PMC_FILE % (args.workload + ("-order%d" % args.node_order if args.node_order > 0 else ""))
     pmc = None
     if os.path.exists(pmc_path):
@@ -572,7 +572,7 @@ def main():
         rays, samples, rays_traced, rows_traced = float(vals[1]), float(vals[2]), float(vals[3]), float(vals[4])
     if rank == 0:
         b_ray = 32.0 + 32.0 * nodes_per_ray + 48.0 * tris_per_ray + 16.0
-        src_hash = importlib.import_module("pathtracer-rs_amd.build").source_hash()
+        src_hash = pkg.build_id()  # the id the LOADED library was built with (sources + every compiler flag)
         pmc, pmc_meta = load_pmc(args.workload, src_hash) if (world == 1 and standard) else (None, {"file": None, "why": "counters are per frame of the standard single-GPU workload"})
         classes = {
             "traversal": class_roofline("traversal", xst.ms_extend + xst.ms_connect, xst.extend_launches + xst.connect_launches, pmc, algorithmic_bytes=xst.rays * b_ray),

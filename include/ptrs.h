@@ -251,6 +251,9 @@ int ptrs_get_option(const char *name, int64_t *value);
 int ptrs_scene_set_option(PtrsScene *scene, const char *name, int64_t value);
 
 int ptrs_abi_version(void);
+/* Identity of this build: a hash over the kernel sources and every compiler flag (pathtracer-rs_amd/build.py).  Measurement files
+ * under profiles/ record it; bench.py takes hardware counters only from a file measured with the library it runs. */
+const char *ptrs_build_id(void);
 int ptrs_abi_sizeof(int which); /* sizeof the ABI structs as compiled (binding self-check) */
 const char *ptrs_last_error(void);
 

@@ -36,27 +36,36 @@ def sources():
         os.path.join(ROOT, "include", "ptrs.h"), os.path.join(ROOT, "include", "ptrs_detmath.h")]
 
 
-def source_hash():
-    """sha256 over what determines the kernels: every file of csrc/, the two headers, the compiler flags.  Counter summaries under
-    profiles/ carry it, and bench.py uses a summary only when it equals the hash of the tree it runs from."""
+def source_hash(extra_flags=()):
+    """sha256 over what determines the kernels: every file of csrc/, the two headers, the compiler flags INCLUDING a build's extra
+    flags (-D tuning macros of A/B builds).  The library carries it (ptrs_build_id(), compiled in as PTRS_BUILD_ID); counter summaries
+    under profiles/ record the id of the library they were measured with, and bench.py uses a summary only when it equals the id of
+    the library it runs."""
     import hashlib
     _gen_tables_inc()
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(" ".join(FLAGS + sorted(extra_flags)).encode())
     for s in sources():
         h.update(os.path.basename(s).encode())
         h.update(open(s, "rb").read())
     return h.hexdigest()[:16]
 
 
-def build(force=False, extra_flags=(), verbose=False):
+def build(force=False, extra_flags=(), verbose=False, out=LIB):
+    """Compiles `out` unless it was built from exactly these sources and flags before (a sidecar file next to the library holds the id
+    it was built with: mtimes say nothing about flags)."""
     _gen_tables_inc()
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in sources()):
-        return LIB
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", LIB, os.path.join(CSRC, "ptrs_hip.hip")]
+    extra_flags = [f for f in extra_flags]
+    bid = source_hash(extra_flags)
+    side = out + ".buildid"
+    if not force and os.path.exists(out) and os.path.exists(side) and open(side).read().strip() == bid:
+        return out
+    cmd = [HIPCC] + FLAGS + extra_flags + ['-DPTRS_BUILD_ID="%s"' % bid, "-o", out, os.path.join(CSRC, "ptrs_hip.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    with open(side, "w") as f:
+        f.write(bid + "\n")
+    return out
 
 
 HEADLESS = os.path.join(HERE, "ptrs_headless")
@@ -74,6 +83,12 @@ def build_host(force=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True, extra_flags=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])
-    print("built", LIB)
-    print("built", build_host(force="--force" in sys.argv))
+    # python -m pathtracer-rs_amd.build [--force] [--variant NAME] [-D... -R... -save-temps]: NAME builds libptrs_NAME.so (A/B builds, PTRS_LIB)
+    extra = [a for a in sys.argv[1:] if a.startswith(("-D", "-R", "-save", "-m"))]
+    if "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print("built", build(force="--force" in sys.argv, verbose=True, extra_flags=extra, out=os.path.join(HERE, "libptrs_%s.so" % name)))
+    else:
+        build(force="--force" in sys.argv, verbose=True, extra_flags=extra)
+        print("built", LIB)
+        print("built", build_host(force="--force" in sys.argv))

@@ -1587,6 +1587,10 @@ template <class F> int guarded(F &&f) {
 extern "C" {
 
 int ptrs_abi_version(void) { return PTRS_ABI_VERSION; }
+#ifndef PTRS_BUILD_ID
+#define PTRS_BUILD_ID "unknown"
+#endif
+const char *ptrs_build_id(void) { return PTRS_BUILD_ID; }
 const char *ptrs_last_error(void) { return g_err.c_str(); }
 
 // struct sizes as compiled, for the binding self-check (tests/test_abi.py)

@@ -36,6 +36,7 @@ def load_library():
                         "There is no CPU fallback for the render path." % so)
     L = C.CDLL(so)
     L.ptrs_last_error.restype = C.c_char_p
+    L.ptrs_build_id.restype = C.c_char_p
     if L.ptrs_abi_version() != 3:
         raise PtrsError("ABI version mismatch")
     structs = [abi.PtrsTexture, abi.PtrsMaterial, abi.PtrsMesh, abi.PtrsLight, abi.PtrsBvhNode, abi.PtrsSceneDesc, abi.PtrsCamera,
@@ -325,3 +326,8 @@ def selftest_div3(mode, n_sets, seed=1, device=0):
     first = np.zeros(10, dtype=np.uint32)
     _check(L.ptrs_selftest_div3(int(device), int(mode), int(n_sets), int(seed), C.byref(bad), C.byref(fast), C.c_void_p(first.ctypes.data)))
     return int(bad.value), int(fast.value), first
+
+
+def build_id():
+    """ptrs_build_id: hash of the kernel sources and compiler flags the loaded library was built from (build.source_hash)."""
+    return load_library().ptrs_build_id().decode()

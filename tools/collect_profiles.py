@@ -6,7 +6,7 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = 0
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "final", "r03_*"))):
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "final", "r04_*"))):
     shutil.copy(f, os.path.join(ROOT, "profiles", os.path.basename(f)))
     n += 1
 print("copied %d files" % n)

@@ -28,6 +28,6 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" \
   timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- $CMD > "$OUT/pmc$i.log" 2>&1 || echo "pass $i failed (see $OUT/pmc$i.log)"
 done
 python3 tools/summarize_pmc.py "$OUT/pmc.csv" "$OUT"/pmc[0-9]
-python3 tools/prof_report.py "$OUT" --json "$OUT/pmc.json" --frames $FR --workload $W --commit "${COMMIT:-$(git rev-parse --short HEAD 2>/dev/null || echo '?')}" > "$OUT/report.txt"
+python3 tools/prof_report.py "$OUT" --json "$OUT/pmc.json" --frames $FR --workload $W > "$OUT/report.txt"
 rm -rf "$OUT"/kt "$OUT"/pmc[0-9]
 echo "done: $OUT"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel digest of one tools/prof.sh directory: time, HBM bytes, what the waves did, what bounds the kernel.
 
-    python tools/prof_report.py gpurun_out/prof_TAG [--json OUT.json] [--frames N] [--workload W] [--commit C]
+    python tools/prof_report.py gpurun_out/prof_TAG [--json OUT.json] [--frames N] [--workload W]
 
 Units (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (FETCH_SIZE is NOT doubled here: the gfx950
 x2 correction is calibrated for 16 B/lane streaming reads only, these kernels gather); SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*
@@ -110,10 +110,10 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         try:
             import importlib
-            src = importlib.import_module("pathtracer-rs_amd.build").source_hash()
+            src = importlib.import_module("pathtracer-rs_amd").build_id()  # of the library the profiled runs loaded (PTRS_LIB or the in-tree build)
         except Exception:
             src = "?"
-        dg["_meta"] = {"frames": int(arg("--frames", "1")), "workload": arg("--workload", "?"), "commit": arg("--commit", "?"), "source_hash": src,
+        dg["_meta"] = {"frames": int(arg("--frames", "1")), "workload": arg("--workload", "?"), "source_hash": src,
                        "command": "tools/prof.sh: rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --workload W --steps FRAMES --profile` (one pipeline lane)",
                        "units": "hbm_bytes = (FETCH_SIZE + WRITE_SIZE) KiB x 1024 as reported (FETCH_SIZE not doubled: 16-byte gathers, uncalibrated); fractions and their bounds: tools/prof_report.py"}
         json.dump(dg, open(arg("--json", "pmc.json"), "w"), indent=1, sort_keys=True)
