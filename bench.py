@@ -602,7 +602,7 @@ def main():
             "classes": classes, "valu_ceiling": ceiling,
             "counters_from": pmc_meta, "counters_usable": bool(d.get("valu_pipe_frac") is not None),
             "timing": "HIP events around every launch of ONE untimed frame on a single pipeline lane (ms_per_frame_single_lane); the timed steps run the default path on %d lanes without events" % int(st.lanes),
-            "single_lane_frame_ms": {"extend": xst.ms_extend, "connect": xst.ms_connect, "shade": xst.ms_shade_kernels, "aux (generate, epilogue, resolve)": xst.ms_aux, "film": xst.ms_film},
+            "single_lane_frame_ms": {"extend": xst.ms_extend, "connect": xst.ms_connect, "shade": xst.ms_shade_kernels, "aux (generate, epilogue, resolve)": xst.ms_aux, "film": xst.ms_film, "tail (fused late rounds)": xst.ms_tail},
             "b_state_bytes_per_path_round": 216, "hbm_copy_measured_gbs": hbm_copy_gbs(torch, dev),
         }
         # film check: rows of the timed film against the committed oracle fixture
@@ -639,7 +639,9 @@ def main():
                        "launch": {"queue_segments_per_pass": st.queue_segments, "passes_per_frame": st.passes, "kernel_launches_per_frame": st.kernel_launches,
                                   "workgroups_last_launch": dict(zip(("extend", "connect", "shade", "aux"), [int(x) for x in st.grid_wgs])),
                                   "resident_workgroups_per_cu": dict(zip(("extend", "connect", "shade", "aux"), [int(x) for x in st.resident_wgs_per_cu])),
-                                  "options": {k: pkg.get_option(k) for k in ("lanes", "grid_mult", "grid_pct", "persist", "refill", "refill_connect", "vote")}}},
+                                  "fused_tail": {"launches_per_frame": int(st.tail_launches), "from_round": (int(st.tail_round) if st.tail_launches else None),
+                                                 "single_lane_frame": {"launches": int(xst.tail_launches), "from_round": (int(xst.tail_round) if xst.tail_launches else None)}},
+                                  "options": {k: pkg.get_option(k) for k in ("lanes", "grid_mult", "grid_pct", "persist", "refill", "refill_connect", "vote", "tail", "tail_at", "tail_paths")}}},
             "roofline": roof,
             "film_check": film_check, "film_check_rel_l2": roof_rel,
         }

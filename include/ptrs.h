@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PTRS_ABI_VERSION 3
+#define PTRS_ABI_VERSION 4
 
 enum {
     PTRS_OK = 0,
@@ -221,6 +221,10 @@ typedef struct PtrsStats {
     uint64_t grid_pct;       /* share of a kernel's resident capacity its launches took (option "grid_pct", or chosen with the lanes) */
     double ms_enqueue;       /* host time from the start of the call until its last pass was enqueued (a job of more passes than lanes
                               * waits for a lane in between); ms_total - ms_enqueue is what the host then waited for the device */
+    /* ABI 4: the fused tail (one launch per pass in which every wave takes its queue segment through all remaining rounds) */
+    double ms_tail;          /* its kernels (PTRS_FLAG_TIMING; their traversal and shading are not in ms_trace / ms_shade) */
+    uint64_t tail_launches;
+    uint64_t tail_round;     /* the round at which the call's last pass handed over, 0xffffffff: it did not */
 } PtrsStats;
 
 enum {

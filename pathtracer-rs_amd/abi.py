@@ -77,7 +77,8 @@ class PtrsStats(C.Structure):
                 ("extend_launches", C.c_uint64), ("connect_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("aux_launches", C.c_uint64),
                 ("film_launches", C.c_uint64), ("error_flags", C.c_uint64), ("node_steps_x64", C.c_uint64), ("node_visits", C.c_uint64),
                 ("tri_steps_x64", C.c_uint64), ("debug", C.c_uint64 * 12), ("queue_segments", C.c_uint64), ("grid_wgs", C.c_uint64 * 4),
-                ("resident_wgs_per_cu", C.c_uint64 * 4), ("lanes", C.c_uint64), ("grid_pct", C.c_uint64), ("ms_enqueue", C.c_double)]
+                ("resident_wgs_per_cu", C.c_uint64 * 4), ("lanes", C.c_uint64), ("grid_pct", C.c_uint64), ("ms_enqueue", C.c_double),
+                ("ms_tail", C.c_double), ("tail_launches", C.c_uint64), ("tail_round", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -279,6 +279,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
         close_pass(lane);
         be.select(lane);
         be.read_counts(counts.data(), pd.it + 1u);
+        be.learn(counts.data(), std::min(pd.it + 1u, max_iters + 1u), pd.n_paths); // (gfx950: the scene's survival profile, which places the next passes' hand-over to the fused tail)
         for (uint32_t i = 0; i <= pd.it && i < max_iters + 1u; ++i) {
             st.rays_extension += counts[(size_t)i * Q_STRIDE + Q_EXT];
             st.rays_shadow += counts[(size_t)i * Q_STRIDE + Q_SHADOW];
@@ -315,7 +316,13 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
                 if (stats) *stats = st;
                 return PTRS_OK;
             }
-            for (; it < std::min(fixed_iters + spare_rounds, max_iters); ++it) round(it);
+            // Rounds as three launches each while the pass is thick; from the round the back end names (gfx950: where its survival profile
+            // expects at most a wave's worth of paths per segment) ONE launch in which every wave takes its segment through all remaining
+            // rounds.  Scenes with null-BSDF skips keep the round-by-round form (their passes stay open for more rounds).
+            const uint32_t n_rounds = std::min(fixed_iters + spare_rounds, max_iters);
+            const uint32_t tail_from = spare_rounds ? 0xffffffffu : be.tail_round(R.n_paths, n_rounds);
+            for (; it < n_rounds && it < tail_from; ++it) round(it);
+            if (it < n_rounds) { be.tail(it, n_rounds); it = n_rounds; }
             // output rows touched by sample rows [r0, r1): pixel row = min_y + sample row, +-2
             const int32_t y0 = std::max(rb, g.min_y + r0 - 2), y1 = std::min(re, g.min_y + r1 - 1 + 2 + 1);
             pending[lane].active = true; pending[lane].it = it; pending[lane].n_paths = R.n_paths; pending[lane].pass_no = pass_no;

@@ -55,6 +55,9 @@ struct Options {
     int shade_lds = 1;        // shade kernels read light records, small scenes' triangle records and the round's Sobol' tables from LDS (0: everything from global memory)
     int env_presample = 1;    // scenes lit by an environment map: the light's samples of a round's vertices are evaluated by k_env_presample ahead of the shade kernels (0: inside them)
     int peer_copy = 1;        // ptrs_render_multi: bands travel device to device (hipMemcpyPeerAsync over xGMI); 0: staged through the host film, the path taken when two devices cannot reach each other (test hook)
+    int tail = 1;             // thin late rounds of a pass run in ONE launch (k_tail: every wave takes its segment through all remaining rounds) where the scene has an instantiation; 0: every round is its three launches
+    int tail_at = -1;         // the round at which a pass hands over to k_tail: -1 = the first round in which the paths expected alive (this scene's survival profile, learned from its last finished pass) are at most tail_paths per segment; k >= 0: round k
+    int tail_paths = 0;       // (tail_at = -1) paths per segment at or below which the tail takes over; 0 = the measured default (TAIL_PATHS_DEFAULT)
     int workspace_pct = 40;   // the render workspace (path state + queues of all lanes) may take this share of the device memory that is free at the call
 };
 Options g_opt;
@@ -63,7 +66,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 0, 8}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 0, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1}, {"env_presample", &Options::env_presample, 0, 1},
+    {"grid_mult", &Options::grid_mult, 0, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1}, {"env_presample", &Options::env_presample, 0, 1}, {"tail", &Options::tail, 0, 1}, {"tail_at", &Options::tail_at, -1, 64}, {"tail_paths", &Options::tail_paths, 0, 1 << 20},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -126,7 +129,7 @@ __device__ inline uint32_t seg_next(uint32_t *ticket, uint32_t G) {
 }
 // counts[(row * Q_STRIDE + q) * G + s]
 __device__ inline uint32_t *seg_count(const DQueues &Q, uint32_t row, int q, uint32_t G, uint32_t s) { return Q.counts + ((size_t)row * Q_STRIDE + (size_t)q) * G + s; }
-enum { TK_EXTEND = 0, TK_CONNECT = 1, TK_SHADE0 = 2, TK_EPILOGUE = 9, TK_RESOLVE = 10, TK_PRESAMPLE = 11 }; // tickets[(row * Q_STRIDE + TK_*) * TK_LAUNCH_WORDS]: the counters of one launch of a pass
+enum { TK_EXTEND = 0, TK_CONNECT = 1, TK_SHADE0 = 2, TK_EPILOGUE = 9, TK_RESOLVE = 10, TK_PRESAMPLE = 11, TK_TAIL = 12 }; // tickets[(row * Q_STRIDE + TK_*) * TK_LAUNCH_WORDS]: the counters of one launch of a pass
 // A round nobody reaches (every path has ended: rounds are enqueued without asking, and for scenes with null-BSDF skips a few more
 // than max_depth + 1) costs its launches only: each kernel looks at the flag and leaves.
 // (Q.alive[row]: the round's "some path is still alive" flag, set by the shade kernels of the round before)
@@ -452,6 +455,50 @@ __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQu
 template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? PTRS_LDS_WAVES : ((GEOM == 0 && DEPTH == 8) ? PTRS_QUAD_WAVES : 0) }; };
 template <int DEPTH, int GEOM> struct TravLds { enum { TOP = GEOM == 0 && DEPTH == 8, V4 = GEOM > 0 ? GEOM : (TOP ? TOP_LDS_STRIDE * QUAD_TOP_NODES : 1) }; }; // quad form with the small stack column: the tree's top lives in LDS
 
+// One queue segment through the extension stage: the wave's refill loop, then (kinds_mask != 0) the segment's epilogue.  Called by
+// k_extend_rf for every segment the wave takes and by k_tail for its segment's remaining rounds.
+template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
+__device__ inline void extend_segment(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask, uint32_t Gn, uint32_t s,
+                                      const GeomTop &GG, const LdsGeom &LG, LdsStack<DEPTH, OVF> &stk, uint32_t &nn, uint32_t &nt, StepCount &stepc) {
+    const uint32_t e0 = s * seg_cap, par = it & 1u; // the segment's rays sit at positions e0 .. e0 + n of the round's ray arrays, in queue order: a refill is one coalesced read, no path slot is looked up
+    const uint32_t n = rfl(*seg_count(Q, it, Q_EXT, Gn, s));
+    uint32_t cursor = 0; // next entry of the segment: wave-uniform, a scalar register
+    bool has = false;    // the lane holds an unfinished ray
+    uint32_t e = 0;      // its position
+    RF_DECL LF_DECL // (per segment: nothing of a ray is live across the epilogue; quad-form kernels use the RF set, LDS-form kernels the LF set)
+    for (;;) {
+        if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this loop
+            u4 v; v.x = hit_pack(r_h.prim, r_h.flags); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
+            pslot(P.hit, e) = v;
+            has = false;
+        }
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (cursor < n && n_idle >= thresh) {
+            const uint32_t i = cursor + lanes_below(idle);
+            if (!has && i < n) {
+                e = e0 + i;
+                const v4 ov = pslot(P.ray_o[par], e), dv = pslot(P.ray_d[par], e);
+                if (GEOM > 0) LF_START(LG, xyz(ov), xyz(dv), PT_INF) else RF_START(xyz(ov), xyz(dv), PT_INF)
+                stk.clear(); has = true;
+            }
+            cursor += n_idle;
+        }
+        if (!__any(has)) break; // every ray of the segment is retired
+        do { // steps until enough lanes are through their rays: only then is there something to retire or refill
+            if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_px, r_py, r_pz, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
+        // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
+        // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
+        // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
+        } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
+    }
+    // The segment's epilogue runs here, behind the wave's last ray, unless kinds_mask = 0 leaves it to k_epilogue: the hits it
+    // reads were written a moment ago by this wave (L2), and its memory latency hides behind the other waves' traversal
+    // instead of filling a kernel of its own.  (The fence orders this wave's hit stores before the loads of other lanes.)
+    if (kinds_mask) { __threadfence_block(); epilogue_wave<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, Gn, s); }
+}
+
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
 __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_extend_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask, uint32_t Gn, uint32_t *ticket) {
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
@@ -463,45 +510,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
     __syncthreads(); // the only barrier of the kernel: from here on the four waves of the workgroup are independent
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
     uint32_t nn = 0, nt = 0; StepCount stepc;
-    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
-        const uint32_t e0 = s * seg_cap, par = it & 1u; // the segment's rays sit at positions e0 .. e0 + n of the round's ray arrays, in queue order: a refill is one coalesced read, no path slot is looked up
-        const uint32_t n = rfl(*seg_count(Q, it, Q_EXT, Gn, s));
-        uint32_t cursor = 0; // next entry of the segment: wave-uniform, a scalar register
-        bool has = false;    // the lane holds an unfinished ray
-        uint32_t e = 0;      // its position
-        RF_DECL LF_DECL // (per segment: nothing of a ray is live across the epilogue; quad-form kernels use the RF set, LDS-form kernels the LF set)
-        for (;;) {
-            if (has && r_cur == REF_NONE) { // retire: the hit record is all that leaves this loop
-                u4 v; v.x = hit_pack(r_h.prim, r_h.flags); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-                pslot(P.hit, e) = v;
-                has = false;
-            }
-            const unsigned long long idle = __ballot(!has);
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (cursor < n && n_idle >= thresh) {
-                const uint32_t i = cursor + lanes_below(idle);
-                if (!has && i < n) {
-                    e = e0 + i;
-                    const v4 ov = pslot(P.ray_o[par], e), dv = pslot(P.ray_d[par], e);
-                    if (GEOM > 0) LF_START(LG, xyz(ov), xyz(dv), PT_INF) else RF_START(xyz(ov), xyz(dv), PT_INF)
-                    stk.clear(); has = true;
-                }
-                cursor += n_idle;
-            }
-            if (!__any(has)) break; // every ray of the segment is retired
-            do { // steps until enough lanes are through their rays: only then is there something to retire or refill
-                if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
-                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_px, r_py, r_pz, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
-            // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
-            // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
-            // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
-            } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
-        }
-        // The segment's epilogue runs here, behind the wave's last ray, unless kinds_mask = 0 leaves it to k_epilogue: the hits it
-        // reads were written a moment ago by this wave (L2), and its memory latency hides behind the other waves' traversal
-        // instead of filling a kernel of its own.  (The fence orders this wave's hit stores before the loads of other lanes.)
-        if (kinds_mask) { __threadfence_block(); epilogue_wave<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, Gn, s); }
-    }
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) extend_segment<FEAT, DEPTH, OVF, GEOM, VOTE>(R, sc, P, Q, it, seg_cap, thresh, kinds_mask, Gn, s, GG, LG, stk, nn, nt, stepc);
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
@@ -509,6 +518,72 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
 // ray (closest hit) of its record.  Shadow-only records (NEE_PRE) are resolved when their ray retires; for the others the
 // answers go to the path state (NEE_OCCLUDED in nee2.w, the MIS hit in `hit`, which the shade stage has consumed by now) and
 // resolve_wave turns them into radiance with full waves behind the segment's last ray.
+// One queue segment through the connection stage (see extend_segment): the wave's refill loop over the segment's NEE records, then
+// (fused_resolve) the MIS resolve of the segment.
+template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
+__device__ inline void connect_segment(const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t fused_resolve, uint32_t Gn, uint32_t s,
+                                       const GeomTop &GG, const LdsGeom &LG, LdsStack<DEPTH, OVF> &stk, uint32_t &nn, uint32_t &nt, StepCount &stepc) {
+    const uint32_t f0 = s * seg_cap; // the segment's records sit at positions f0 .. f0 + n of the NEE arrays, in the order of its queue entries
+    const uint32_t n = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
+    uint32_t cursor = 0;
+    bool has = false, shadow_phase = false, setup = false;
+    uint32_t pid = 0, fl = 0, f = 0;
+    f3 pre_l = splat3(0.0f); // NEE_PRE records: the path's radiance WITH the record's contribution (both fetched with the ray, added at once: three registers live across the traversal instead of seven), stored if the ray comes through
+    RF_DECL LF_DECL // (per segment: nothing of a ray is live across the resolve)
+    for (;;) {
+        if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
+            if (shadow_phase) {
+                if (fl & NEE_PRE) { // a shadow-only record is resolved here: l += beta * nLights * ld unless the ray was blocked (integrator.rs:66-78, 444-446)
+                    if (!r_hit) pslot(P.L, pid) = mkv4(pre_l, 0.0f); // (L.w is never anything but generate_item's 0)
+                    has = false;
+                } else {
+                    if (r_hit) reinterpret_cast<uint32_t *>(&pslot(P.nee2, f))[3] |= NEE_OCCLUDED << 24;
+                    if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
+                }
+            } else {
+                u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
+                pslot(P.nhit, f) = v;
+                has = false;
+            }
+        }
+        // Ray setup (five divisions) is the expensive part of taking a ray, and it runs with the lanes that need it only: a lane
+        // whose shadow ray is done waits for its MIS ray's setup until the idle and the waiting lanes together reach the refill
+        // threshold (or nobody else is working), so that one pass of the setup code serves a batch of lanes, not one or two.
+        const unsigned long long idle = __ballot(!has);
+        const bool batch = (uint32_t)__popcll(__ballot(!has || setup)) >= thresh || !__any(has && !setup);
+        if (batch && cursor < n && idle) {
+            const uint32_t i = cursor + lanes_below(idle);
+            if (!has && i < n) {
+                f = f0 + i;
+                const uint32_t entry = pslot(Q.nee, f); // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
+                pid = entry & NEE_Q_PID;
+                fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
+#if defined(PTRS_ABL_CONNECT_ONLY) && PTRS_ABL_CONNECT_ONLY == 1
+                fl &= ~(uint32_t)NEE_MIS; // diagnostic build: the shadow rays alone (timing only: wrong radiance)
+#elif defined(PTRS_ABL_CONNECT_ONLY) && PTRS_ABL_CONNECT_ONLY == 2
+                fl &= ~(uint32_t)NEE_SHADOW; // diagnostic build: the MIS rays alone
+#endif
+                if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
+            }
+            cursor += (uint32_t)__popcll(idle);
+        }
+        if (batch && setup) {
+            const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
+            const v4 o = pslot(po, f), d = pslot(pd, f);
+            if (shadow_phase && (fl & NEE_PRE)) { const f3 c = mk3(d.w, o.w, pslot(P.pre_z, f)); pre_l = xyz(pslot(P.L, pid)) + c; } // shade_item's packing of a shadow-only record; resolve_item's sum
+            if (GEOM > 0) LF_START(LG, xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF) else RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
+            stk.clear(); setup = false;
+        }
+        if (!__any(has)) break;
+        do {
+            if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+            else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_px, r_py, r_pz, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
+        } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh)); // (see k_extend_rf)
+    }
+    // records with a MIS ray are resolved behind the wave's last ray (see k_extend_rf's epilogue), unless fused_resolve = 0 leaves them to k_resolve
+    if (fused_resolve) { __threadfence_block(); resolve_wave<FEAT>(sc, P, Q, it, seg_cap, Gn, s); }
+}
+
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
 __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_connect_rf(DParams R, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t fused_resolve, uint32_t Gn, uint32_t *ticket) {
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
@@ -520,67 +595,7 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_co
     __syncthreads();
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
     uint32_t nn = 0, nt = 0; StepCount stepc;
-    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
-        const uint32_t f0 = s * seg_cap; // the segment's records sit at positions f0 .. f0 + n of the NEE arrays, in the order of its queue entries
-        const uint32_t n = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
-        uint32_t cursor = 0;
-        bool has = false, shadow_phase = false, setup = false;
-        uint32_t pid = 0, fl = 0, f = 0;
-        f3 pre_l = splat3(0.0f); // NEE_PRE records: the path's radiance WITH the record's contribution (both fetched with the ray, added at once: three registers live across the traversal instead of seven), stored if the ray comes through
-        RF_DECL LF_DECL // (per segment: nothing of a ray is live across the resolve)
-        for (;;) {
-            if (has && r_cur == REF_NONE && !setup) { // the ray in flight is done
-                if (shadow_phase) {
-                    if (fl & NEE_PRE) { // a shadow-only record is resolved here: l += beta * nLights * ld unless the ray was blocked (integrator.rs:66-78, 444-446)
-                        if (!r_hit) pslot(P.L, pid) = mkv4(pre_l, 0.0f); // (L.w is never anything but generate_item's 0)
-                        has = false;
-                    } else {
-                        if (r_hit) reinterpret_cast<uint32_t *>(&pslot(P.nee2, f))[3] |= NEE_OCCLUDED << 24;
-                        if (fl & NEE_MIS) { shadow_phase = false; setup = true; } else has = false;
-                    }
-                } else {
-                    u4 v; v.x = (uint32_t)(r_hit ? r_h.prim : -1); v.y = f2u(r_h.b0); v.z = f2u(r_h.b1); v.w = f2u(r_h.b2);
-                    pslot(P.nhit, f) = v;
-                    has = false;
-                }
-            }
-            // Ray setup (five divisions) is the expensive part of taking a ray, and it runs with the lanes that need it only: a lane
-            // whose shadow ray is done waits for its MIS ray's setup until the idle and the waiting lanes together reach the refill
-            // threshold (or nobody else is working), so that one pass of the setup code serves a batch of lanes, not one or two.
-            const unsigned long long idle = __ballot(!has);
-            const bool batch = (uint32_t)__popcll(__ballot(!has || setup)) >= thresh || !__any(has && !setup);
-            if (batch && cursor < n && idle) {
-                const uint32_t i = cursor + lanes_below(idle);
-                if (!has && i < n) {
-                    f = f0 + i;
-                    const uint32_t entry = pslot(Q.nee, f); // path slot | NEE_Q_* (which rays the record holds: no flags word to load before them)
-                    pid = entry & NEE_Q_PID;
-                    fl = ((entry & NEE_Q_SHADOW) ? (uint32_t)NEE_SHADOW : 0u) | ((entry & NEE_Q_MIS) ? (uint32_t)NEE_MIS : 0u) | ((entry & NEE_Q_PRE) ? (uint32_t)NEE_PRE : 0u);
-#if defined(PTRS_ABL_CONNECT_ONLY) && PTRS_ABL_CONNECT_ONLY == 1
-                    fl &= ~(uint32_t)NEE_MIS; // diagnostic build: the shadow rays alone (timing only: wrong radiance)
-#elif defined(PTRS_ABL_CONNECT_ONLY) && PTRS_ABL_CONNECT_ONLY == 2
-                    fl &= ~(uint32_t)NEE_SHADOW; // diagnostic build: the MIS rays alone
-#endif
-                    if (fl & (NEE_SHADOW | NEE_MIS)) { shadow_phase = (fl & NEE_SHADOW) != 0; setup = true; has = true; }
-                }
-                cursor += (uint32_t)__popcll(idle);
-            }
-            if (batch && setup) {
-                const v4 *po = shadow_phase ? P.sh_o : P.mis_o, *pd = shadow_phase ? P.sh_d : P.mis_d; // one copy of the setup code for both kinds of ray
-                const v4 o = pslot(po, f), d = pslot(pd, f);
-                if (shadow_phase && (fl & NEE_PRE)) { const f3 c = mk3(d.w, o.w, pslot(P.pre_z, f)); pre_l = xyz(pslot(P.L, pid)) + c; } // shade_item's packing of a shadow-only record; resolve_item's sum
-                if (GEOM > 0) LF_START(LG, xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF) else RF_START(xyz(o), xyz(d), shadow_phase ? PT_SHADOW_TMAX : PT_INF)
-                stk.clear(); setup = false;
-            }
-            if (!__any(has)) break;
-            do {
-                if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
-                else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_px, r_py, r_pz, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, shadow_phase, stepc);
-            } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh)); // (see k_extend_rf)
-        }
-        // records with a MIS ray are resolved behind the wave's last ray (see k_extend_rf's epilogue), unless fused_resolve = 0 leaves them to k_resolve
-        if (fused_resolve) { __threadfence_block(); resolve_wave<FEAT>(sc, P, Q, it, seg_cap, Gn, s); }
-    }
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) connect_segment<FEAT, DEPTH, OVF, GEOM, VOTE>(sc, P, Q, it, seg_cap, thresh, fused_resolve, Gn, s, GG, LG, stk, nn, nt, stepc);
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
@@ -746,17 +761,13 @@ struct ShadeCtxLds {
     }
 };
 
-template <int MAT, int FEAT, bool ENVPRE>
-__global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
-    constexpr uint32_t NPF = (FEAT & FEAT_INFINITE) ? 7u : 5u; // + the vertex's presampled environment-light sample
-    __shared__ v4 lds_pf[NPF * BLOCK]; // the next item's path state per thread, filled by LDS-DMA
-    __shared__ uint32_t lds_sob[SH_SOB_WORDS];
-    __shared__ v4 lds_tri[SH_TRI_V4];
-    __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
-    constexpr bool MARG = (FEAT & FEAT_INFINITE) && !ENVPRE; // the in-kernel walk of the environment light's distribution needs its marginal tables
-    __shared__ float lds_marg[MARG ? SH_MARG_WORDS : 1];
-    bool err_dim = false;
-    if (round_is_dead(Q, it)) return;
+// The shade kernels' LDS: the next item's path state per thread (filled by LDS-DMA) and the read-only tables.
+template <int FEAT, bool ENVPRE> struct ShadeLdsSizes { enum : uint32_t { NPF = (FEAT & FEAT_INFINITE) ? 7u : 5u /* + the vertex's presampled environment-light sample */, MARG = ((FEAT & FEAT_INFINITE) && !ENVPRE) ? 1u : 0u /* the in-kernel walk of the environment light's distribution needs its marginal tables */ }; };
+// Staging of the tables, once per workgroup (the caller's barrier makes them visible); sob_n = 0 stages no Sobol' window (k_tail:
+// its waves are in different rounds, their draws read the global tables).
+template <int FEAT, bool ENVPRE>
+__device__ inline ShadeCtxLds<ENVPRE> stage_shade_tables(const DSampler &S, const DScene &sc, const ShadeLdsCfg &cfg, uint32_t *lds_sob, v4 *lds_tri, v4 *lds_light, float *lds_marg) {
+    constexpr bool MARG = ShadeLdsSizes<FEAT, ENVPRE>::MARG != 0;
     {
         const uint32_t stride = sob_stride(cfg.sob_nib), nw = cfg.sob_nib * 16u;
         for (uint32_t i = threadIdx.x; i < cfg.sob_n * stride; i += BLOCK) { const uint32_t d = i / stride, w = i - d * stride; lds_sob[i] = w < nw ? S.nibtab[((size_t)(cfg.sob_lo + d) * SOBOL_NIBBLES) * 16u + w] : 0u; }
@@ -771,18 +782,23 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
             for (uint32_t i = threadIdx.x; i < gv + 1u; i += BLOCK) lds_marg[2u * SH_MARG_N + 1u + i] = sc.distdata[Le.mguide_off + i];
         }
     }
-    __syncthreads(); // the only barrier: the tables are staged once per workgroup, then its four waves work through segments on their own
     ShadeCtxLds<ENVPRE> X; X.sob = (lds_u32 *)lds_sob; X.tris = (lds_v4 *)lds_tri; X.lights = (lds_v4 *)lds_light; X.cfg = cfg;
     if (!MARG) X.cfg.marg_li = 0xffffffffu;
     X.marg.func = lds_marg; X.marg.cdf = lds_marg + (MARG ? SH_MARG_N : 0); X.marg.guide = lds_marg + (MARG ? 2 * SH_MARG_N + 1 : 0);
-#ifdef PTRS_STAMPS
-    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
-#endif
-    // Software pipeline through LDS.  A vertex needs 80 bytes of its path out of HBM before it can start, and nothing else
-    // of this stage waits for HBM: the wave asks for the NEXT item's five vectors with LDS-DMA loads (global_load_lds_dwordx4:
-    // no registers held while they fly) before it shades the current item, and shade_item waits for them right before it issues
-    // its stores (before_stores) -- by then they have had a whole vertex's time to arrive.  The queue entry is read two items
-    // ahead.  Vector k of wave w sits at lds_pf[(k * 4 + w) * 64 + lane].
+    return X;
+}
+
+// One queue segment of one material bucket through the shade stage.  Called by k_shade for every segment the wave takes and by
+// k_tail for its segment's remaining rounds.
+// Software pipeline through LDS.  A vertex needs 80 bytes of its path out of HBM before it can start, and nothing else
+// of this stage waits for HBM: the wave asks for the NEXT item's five vectors with LDS-DMA loads (global_load_lds_dwordx4:
+// no registers held while they fly) before it shades the current item, and shade_item waits for them right before it issues
+// its stores (before_stores) -- by then they have had a whole vertex's time to arrive.  The queue entry is read two items
+// ahead.  Vector k of wave w sits at lds_pf[(k * 4 + w) * 64 + lane].
+template <int MAT, int FEAT, bool ENVPRE>
+__device__ inline void shade_segment(const DParams &R, const DSampler &S, const DCamera &C, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t Gn, uint32_t s,
+                                     const ShadeCtxLds<ENVPRE> &X, v4 *lds_pf, bool &err_dim PT_STAMP_PARAMS) {
+    const ShadeLdsCfg &cfg = X.cfg;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, par = it & 1u;
     auto dma = [&](const MatEntry &m) { // the vertex's ray, throughput and hit at its position in the round's extension queue, the path's constants at its slot
         typedef __attribute__((address_space(1))) const void gptr; typedef __attribute__((address_space(3))) void lptr;
@@ -796,68 +812,142 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
             __builtin_amdgcn_global_load_lds((gptr *)&pslot(P.pre1, m.e), (lptr *)(lds_pf + (6u * 4u + wv) * 64u), 16, 0, 0);
         }
     };
-    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
-        const MatEntry *__restrict__ queue = Q.mat[MAT] + (size_t)s * seg_cap;
-        const uint32_t n = rfl(*seg_count(Q, it, Q_MAT0 + MAT, Gn, s));
-        if (n == 0) continue;
-        // several material kernels append to the same output segments one after the other
-        const uint32_t next_base = rfl(*seg_count(Q, it + 1u, Q_EXT, Gn, s)), nee_base = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
-        const uint32_t e_next0 = s * seg_cap + next_base, f0 = s * seg_cap + nee_base; // where this launch's first continuing ray / first NEE record goes
-        uint32_t c_next = 0, c_nee = 0, c_shadow = 0, c_mis = 0; // the segment's output counters: wave-uniform, scalar registers
-        uint32_t i = lane;
-        MatEntry m, m1; m.e = m.pid = m1.e = m1.pid = 0;
-        if (i < n) { m = pslot(queue, i); dma(m); }
-        if (i + 64u < n) m1 = pslot(queue, i + 64u);
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first item's state is in LDS
-        while (i < n) {
-            PathIn in;
-            {
-                lds_v4 *q = (lds_v4 *)lds_pf + threadIdx.x;
-                if (FEAT & FEAT_IMAGE) in.ro = X.ld(q); else in.ro = mkv4(splat3(0.0f), 0.0f);
-                in.rd = X.ld(q + BLOCK); in.beta = X.ld(q + 2 * BLOCK);
-                const v4 a = X.ld(q + 3 * BLOCK), c = X.ld(q + 4 * BLOCK);
-                in.st.x = f2u(a.x); in.st.y = f2u(a.y); in.st.z = f2u(a.z); in.st.w = f2u(a.w);
-                in.hit.x = f2u(c.x); in.hit.y = f2u(c.y); in.hit.z = f2u(c.z); in.hit.w = f2u(c.w);
-                if ((FEAT & FEAT_INFINITE) && cfg.pre_li != 0xffffffffu) { in.pre0 = X.ld(q + 5 * BLOCK); in.pre1 = X.ld(q + 6 * BLOCK); } else in.pre0 = in.pre1 = mkv4(splat3(0.0f), 0.0f);
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS reads are done before the next DMA overwrites the buffer
-            const uint32_t i2 = i + 64u;
-            if (i2 < n) dma(m1);
-            MatEntry m2; m2.e = m2.pid = 0;
-            if (i2 + 64u < n) m2 = pslot(queue, i2 + 64u);
+    const MatEntry *__restrict__ queue = Q.mat[MAT] + (size_t)s * seg_cap;
+    const uint32_t n = rfl(*seg_count(Q, it, Q_MAT0 + MAT, Gn, s));
+    if (n == 0) return;
+    // several material kernels append to the same output segments one after the other
+    const uint32_t next_base = rfl(*seg_count(Q, it + 1u, Q_EXT, Gn, s)), nee_base = rfl(*seg_count(Q, it, Q_NEE, Gn, s));
+    const uint32_t e_next0 = s * seg_cap + next_base, f0 = s * seg_cap + nee_base; // where this launch's first continuing ray / first NEE record goes
+    uint32_t c_next = 0, c_nee = 0, c_shadow = 0, c_mis = 0; // the segment's output counters: wave-uniform, scalar registers
+    uint32_t i = lane;
+    MatEntry m, m1; m.e = m.pid = m1.e = m1.pid = 0;
+    if (i < n) { m = pslot(queue, i); dma(m); }
+    if (i + 64u < n) m1 = pslot(queue, i + 64u);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first item's state is in LDS
+    while (i < n) {
+        PathIn in;
+        {
+            lds_v4 *q = (lds_v4 *)lds_pf + threadIdx.x;
+            if (FEAT & FEAT_IMAGE) in.ro = X.ld(q); else in.ro = mkv4(splat3(0.0f), 0.0f);
+            in.rd = X.ld(q + BLOCK); in.beta = X.ld(q + 2 * BLOCK);
+            const v4 a = X.ld(q + 3 * BLOCK), c = X.ld(q + 4 * BLOCK);
+            in.st.x = f2u(a.x); in.st.y = f2u(a.y); in.st.z = f2u(a.z); in.st.w = f2u(a.w);
+            in.hit.x = f2u(c.x); in.hit.y = f2u(c.y); in.hit.z = f2u(c.z); in.hit.w = f2u(c.w);
+            if ((FEAT & FEAT_INFINITE) && cfg.pre_li != 0xffffffffu) { in.pre0 = X.ld(q + 5 * BLOCK); in.pre1 = X.ld(q + 6 * BLOCK); } else in.pre0 = in.pre1 = mkv4(splat3(0.0f), 0.0f);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the LDS reads are done before the next DMA overwrites the buffer
+        const uint32_t i2 = i + 64u;
+        if (i2 < n) dma(m1);
+        MatEntry m2; m2.e = m2.pid = 0;
+        if (i2 + 64u < n) m2 = pslot(queue, i2 + 64u);
 #ifdef PTRS_STAMPS
-            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, m.pid, in, X, stamp_acc, stamp_last);
+        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, m.pid, in, X, stamp_acc, stamp_last);
 #else
-            const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, m.pid, in, X);
+        const ShadeResult r = shade_item<MAT, FEAT>(R, S, C, sc, P, m.pid, in, X);
 #endif
-            err_dim = err_dim || r.err_dim;
-            // the vertex's stores: the continuing ray at the position the path takes in the next round's extension queue, the NEE record at
-            // the position of its queue entry -- consecutive positions for the lanes of the wave, whole 128-byte lines
-            const uint32_t e_next = e_next0 + wave_push(c_next, r.next), f = f0 + wave_push(c_nee, r.nee);
-            X.before_stores();
-            store_shade_out(P, par ^ 1u, r, e_next, f);
-            if (r.next) pslot(Q.ext[par ^ 1u], e_next) = m.pid;
-            if (r.nee) pslot(Q.nee, f) = r.nee_entry(m.pid);
+        err_dim = err_dim || r.err_dim;
+        // the vertex's stores: the continuing ray at the position the path takes in the next round's extension queue, the NEE record at
+        // the position of its queue entry -- consecutive positions for the lanes of the wave, whole 128-byte lines
+        const uint32_t e_next = e_next0 + wave_push(c_next, r.next), f = f0 + wave_push(c_nee, r.nee);
+        X.before_stores();
+        store_shade_out(P, par ^ 1u, r, e_next, f);
+        if (r.next) pslot(Q.ext[par ^ 1u], e_next) = m.pid;
+        if (r.nee) pslot(Q.nee, f) = r.nee_entry(m.pid);
 #ifdef PTRS_STAMPS
-            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[8] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; }
+        { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[8] += t_ - stamp_last; stamp_last = t_; stamp_acc[10] += 1; }
 #endif
-            c_shadow += (uint32_t)__popcll(__ballot(r.shadow));
-            c_mis += (uint32_t)__popcll(__ballot(r.mis));
-            i = i2; m = m1; m1 = m2;
-        }
-        if (lane == 0) { // the wave is the segment's only writer in this launch
-            *seg_count(Q, it + 1u, Q_EXT, Gn, s) = next_base + c_next;
-            if (c_next) Q.alive[it + 1u] = 1u;
-            *seg_count(Q, it, Q_NEE, Gn, s) = nee_base + c_nee;
-            *seg_count(Q, it, Q_SHADOW, Gn, s) += c_shadow;
-            *seg_count(Q, it, Q_MIS, Gn, s) += c_mis;
-        }
+        c_shadow += (uint32_t)__popcll(__ballot(r.shadow));
+        c_mis += (uint32_t)__popcll(__ballot(r.mis));
+        i = i2; m = m1; m1 = m2;
     }
+    if (lane == 0) { // the wave is the segment's only writer in this launch
+        *seg_count(Q, it + 1u, Q_EXT, Gn, s) = next_base + c_next;
+        if (c_next) Q.alive[it + 1u] = 1u;
+        *seg_count(Q, it, Q_NEE, Gn, s) = nee_base + c_nee;
+        *seg_count(Q, it, Q_SHADOW, Gn, s) += c_shadow;
+        *seg_count(Q, it, Q_MIS, Gn, s) += c_mis;
+    }
+}
+
+template <int MAT, int FEAT, bool ENVPRE>
+__global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DParams R, DSampler S, DCamera C, DScene sc, DPaths P, DQueues Q, uint32_t it, uint32_t seg_cap, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
+    __shared__ v4 lds_pf[ShadeLdsSizes<FEAT, ENVPRE>::NPF * BLOCK]; // the next item's path state per thread, filled by LDS-DMA
+    __shared__ uint32_t lds_sob[SH_SOB_WORDS];
+    __shared__ v4 lds_tri[SH_TRI_V4];
+    __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
+    __shared__ float lds_marg[ShadeLdsSizes<FEAT, ENVPRE>::MARG ? SH_MARG_WORDS : 1];
+    bool err_dim = false;
+    if (round_is_dead(Q, it)) return;
+    const ShadeCtxLds<ENVPRE> X = stage_shade_tables<FEAT, ENVPRE>(S, sc, cfg, lds_sob, lds_tri, lds_light, lds_marg);
+    __syncthreads(); // the only barrier: the tables are staged once per workgroup, then its four waves work through segments on their own
+#ifdef PTRS_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) shade_segment<MAT, FEAT, ENVPRE>(R, S, C, sc, P, Q, it, seg_cap, Gn, s, X, lds_pf, err_dim, stamp_acc, stamp_last);
+#else
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) shade_segment<MAT, FEAT, ENVPRE>(R, S, C, sc, P, Q, it, seg_cap, Gn, s, X, lds_pf, err_dim);
+#endif
     if (err_dim) atomicOr(&Q.stats[CNT_ERR], (unsigned long long)PTRS_ERRFLAG_SOBOL_DIM);
 #ifdef PTRS_STAMPS
     { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[11] += t_ - stamp_last; }
-    if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&Q.stats[CNT_STAMP0 + k], stamp_acc[k]);
+    if ((threadIdx.x & 63u) == 0) for (int k = 0; k < 12; ++k) atomicAdd(&Q.stats[CNT_STAMP0 + k], stamp_acc[k]);
 #endif
+}
+
+// ---- the fused tail: a wave takes ITS segment through all remaining rounds --------------------------------------------------------
+// A pass is max_depth + 1 rounds of extend -> shade -> connect, three dependent launches each; after the first few rounds Russian
+// roulette and the depth of the scene have left a handful of paths per segment, and every launch of such a round costs 30-60 us
+// whatever it holds (dispatch, tables into LDS, tickets, the drain): ~7 ms per render call that do not shrink with the job
+// (tools/fixed_cost_probe.py), which is what caps the strong scaling of a frame over N GPUs.  But segments are wave-private through
+// every stage -- the wave that consumes segment s of one stage appends only to segment s of the next -- so once a pass is thin no
+// grid-wide ordering is needed at all: ONE launch in which each wave runs extend -> shade -> connect for its own segment, round
+// after round, until the segment is empty.  Same stage functions (extend_segment, shade_segment, connect_segment) on the same
+// queue positions in the same order: same bits.  A workgroup-scope fence between the stages orders the wave's stores before its
+// next stage's loads (what epilogue_wave / resolve_wave rely on already).  The Sobol' window of the shade stage is per round and
+// the waves of a workgroup are in different rounds: draws read the global tables (sob_n = 0).
+// Instantiated for scenes of ONE material bucket whose traversal kernels are the lean ones (Cornell: Matte; colonnade: Disney +
+// image textures); two workgroups per CU (the Matte shade stage's registers, the LDS of both stages).
+template <int MAT, int FEAT, int GEOM, bool OVF>
+__global__ __launch_bounds__(BLOCK, 2) void k_tail(DParams R, DSampler S, DCamera C, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it0, uint32_t it_end, uint32_t seg_cap, uint32_t thresh_e, uint32_t thresh_c,
+                                                   uint32_t kinds_mask, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
+    constexpr int DEPTH = 8, FEAT_T = FEAT_SIMPLE;
+    constexpr bool VOTE_C = GEOM == 0; // (the launch policy's defaults: phase voting in the connection stage for quad-form scenes only)
+    __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
+    __shared__ v4 lds_geom[TravLds<DEPTH, GEOM>::V4];
+    __shared__ v4 lds_pf[ShadeLdsSizes<FEAT, false>::NPF * BLOCK];
+    __shared__ uint32_t lds_sob[4];
+    __shared__ v4 lds_tri[SH_TRI_V4];
+    __shared__ v4 lds_light[SH_LIGHTS * SH_LIGHT_V4];
+    __shared__ float lds_marg[ShadeLdsSizes<FEAT, false>::MARG ? SH_MARG_WORDS : 1];
+    if (round_is_dead(Q, it0)) return;
+    LdsGeom LG; LG.root = LG.tri0 = LG.tri_copy = 0;
+    const GeomTop GG = stage_top(sc, lds_geom, TravLds<DEPTH, GEOM>::TOP);
+    if (GEOM > 0) LG = stage_lds_form(sc, lds_geom);
+    cfg.sob_n = 0;
+    const ShadeCtxLds<false> X = stage_shade_tables<FEAT, false>(S, sc, cfg, lds_sob, lds_tri, lds_light, lds_marg);
+    __syncthreads(); // the only barrier
+    LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
+    uint32_t nn = 0, nt = 0; StepCount stepc;
+    bool err_dim = false;
+#ifdef PTRS_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
+        for (uint32_t it = it0; it < it_end; ++it) {
+            if (rfl(*(volatile uint32_t *)seg_count(Q, it, Q_EXT, Gn, s)) == 0u) break; // nobody of this segment reached the round
+            extend_segment<FEAT_T, DEPTH, OVF, GEOM, true>(R, sc, P, Q, it, seg_cap, thresh_e, kinds_mask, Gn, s, GG, LG, stk, nn, nt, stepc);
+            __threadfence_block();
+#ifdef PTRS_STAMPS
+            shade_segment<MAT, FEAT, false>(R, S, C, sc, P, Q, it, seg_cap, Gn, s, X, lds_pf, err_dim, stamp_acc, stamp_last);
+#else
+            shade_segment<MAT, FEAT, false>(R, S, C, sc, P, Q, it, seg_cap, Gn, s, X, lds_pf, err_dim);
+#endif
+            __threadfence_block();
+            connect_segment<FEAT_T, DEPTH, OVF, GEOM, VOTE_C>(sc, P, Q, it, seg_cap, thresh_c, 1u, Gn, s, GG, LG, stk, nn, nt, stepc);
+            __threadfence_block();
+        }
+    }
+    if (err_dim) atomicOr(&Q.stats[CNT_ERR], (unsigned long long)PTRS_ERRFLAG_SOBOL_DIM);
+    if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
 // The environment light's samples of a round's vertices, ahead of the round's shade kernels.  Which light a vertex samples and with
@@ -1169,6 +1259,7 @@ struct PtrsScene {
     std::map<std::string, int> overrides;  // ptrs_scene_set_option: this scene's renders take these instead of the process-wide values
     std::map<const void *, int> occupancy; // workgroups per CU by kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor), asked once
     uint32_t stack_lds = 16; // LDS stack entries per lane: 8 when the tree allows it, else 16 (+ spill)
+    std::vector<double> alive_frac; // survival profile of this scene's paths: share of a pass's paths that reached round k, from the last finished pass (HipBackend::learn); empty until a pass has finished
     // render workspace, grown on demand and reused across calls
     DevBuf ws[MAX_LANES][32];   // per pipeline lane
     DevBuf counts[MAX_LANES], totals[MAX_LANES], tickets[MAX_LANES];
@@ -1282,8 +1373,8 @@ struct HipBackend {
         if (ev_next == ps->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { rc = PTRS_ERR_DEVICE; return nullptr; } ps->ev_pool.push_back(e); }
         return ps->ev_pool[ev_next++];
     }
-    enum { T_EXTEND = 0, T_AUX = 1, T_FILM = 2, T_CONNECT = 3, T_SHADE = 4, T_NUM = 5 }; // kernel classes of the timing spans
-    uint64_t cat_launches[T_NUM] = {0, 0, 0, 0, 0};
+    enum { T_EXTEND = 0, T_AUX = 1, T_FILM = 2, T_CONNECT = 3, T_SHADE = 4, T_TAIL = 5, T_NUM = 6 }; // kernel classes of the timing spans
+    uint64_t cat_launches[T_NUM] = {0, 0, 0, 0, 0, 0};
     void t0(int cat) { if (flags & PTRS_FLAG_TIMING) { Span s; s.cat = cat; s.a = ev(); s.b = ev(); if (s.a) (void)hipEventRecord(s.a, stream); spans.push_back(s); } ++launches; ++cat_launches[cat]; if (cat == T_EXTEND || cat == T_CONNECT) ++trace_launches; }
     void t1() { if (flags & PTRS_FLAG_TIMING) { if (spans.back().b) (void)hipEventRecord(spans.back().b, stream); } }
     int grid_for(uint32_t n) const { uint32_t g = (n + BLOCK - 1) / BLOCK; if (g < 1) g = 1; const uint32_t gm = (uint32_t)ps->n_cu * 8u; return (int)(g > gm ? gm : g); }
@@ -1291,7 +1382,7 @@ struct HipBackend {
     // Workgroups of a persistent queue kernel: what fits the machine at once (the kernel's resident workgroups per CU x CUs), never
     // more than the segments need (4 waves = 4 segments per workgroup).  A launch that over-estimates the residency loses nothing:
     // workgroups that start late find the ticket counter exhausted and leave.
-    uint32_t last_grid[T_NUM] = {0, 0, 0, 0, 0}, last_per_cu[T_NUM] = {0, 0, 0, 0, 0}; // last launch of each class (PtrsStats)
+    uint32_t last_grid[T_NUM] = {0, 0, 0, 0, 0, 0}, last_per_cu[T_NUM] = {0, 0, 0, 0, 0, 0}; // last launch of each class (PtrsStats)
     template <class F> int wgs_per_cu(F fn) {
         const void *key = reinterpret_cast<const void *>(fn);
         auto itr = ps->occupancy.find(key);
@@ -1479,6 +1570,48 @@ struct HipBackend {
         else hipLaunchKernelGGL((k_env_presample<FEAT_FULL>), dim3(persistent_grid(k_env_presample<FEAT_FULL>, T_AUX)), dim3(BLOCK), 0, stream, S, sc, P, Q, it, seg_cap, nee_kinds, li, shade_cfg(it), G, ticket(it, TK_PRESAMPLE));
         t1();
     }
+    // ---- the fused tail (k_tail) ----
+    typedef void (*TailFn)(DParams, DSampler, DCamera, DScene, StackSpill, DPaths, DQueues, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, ShadeLdsCfg, uint32_t, uint32_t *);
+    enum : uint32_t { TAIL_PATHS_DEFAULT = 192 }; // measured (tools/tail_sweep.sh): flat between 64 and 384 paths per segment for every job size; below, thin rounds stay three launches each, above, thick rounds run at the tail's two waves per SIMD
+    TailFn tail_fn() { // the instantiation for this scene, or null: one material bucket, the lean traversal kernels, the 8-entry stack column, the fused epilogue / resolve
+        if (!opt.tail || !opt.fused_epilogue || !opt.fused_resolve || !opt.shade_lds || !opt.persist || ps->stack_lds != 8 || feat_trace != FEAT_SIMPLE || S.kind != PTRS_SAMPLER_SOBOL) return nullptr;
+        int kind = -1;
+        for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) { if (kind >= 0) return nullptr; kind = k; }
+        const bool ovf = ps->spill.p != nullptr;
+        if (kind == PTRS_MAT_MATTE && feat == FEAT_SIMPLE) {
+            if (geom4 <= 640) return ovf ? (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 640, true> : (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 640, false>;
+            if (geom4 <= 1536) return ovf ? (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 1536, true> : (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 1536, false>;
+            return ovf ? (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 0, true> : (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 0, false>;
+        }
+        if (kind == PTRS_MAT_DISNEY && feat == FEAT_IMG && geom4 > 1536) return ovf ? (TailFn)k_tail<PTRS_MAT_DISNEY, FEAT_IMG, 0, true> : (TailFn)k_tail<PTRS_MAT_DISNEY, FEAT_IMG, 0, false>;
+        return nullptr;
+    }
+    // The round at which the current pass (pass_begin has run: G is known) hands over to the tail, or 0xffffffff: the first round whose
+    // expected alive paths -- this scene's survival profile x the pass's paths -- are at most tail_paths per segment.  No profile yet
+    // (the scene's first render): no tail; the results do not depend on the choice.
+    uint32_t tail_round(uint32_t n_paths, uint32_t n_rounds) {
+        if (!tail_fn()) return 0xffffffffu;
+        if (opt.tail_at >= 0) return (uint32_t)opt.tail_at < n_rounds ? (uint32_t)opt.tail_at : 0xffffffffu;
+        const double limit = (double)(opt.tail_paths > 0 ? (uint32_t)opt.tail_paths : (uint32_t)TAIL_PATHS_DEFAULT) * (double)G;
+        const std::vector<double> &f = ps->alive_frac;
+        for (uint32_t it = 0; it < n_rounds && it < f.size(); ++it) if (f[it] * (double)n_paths <= limit) return it;
+        return 0xffffffffu;
+    }
+    uint32_t tail_at_last = 0xffffffffu;
+    void tail(uint32_t it0, uint32_t it_end) {
+        const TailFn fn = tail_fn();
+        if (!fn) return;
+        t0(T_TAIL);
+        hipLaunchKernelGGL(fn, dim3(persistent_grid(fn, T_TAIL)), dim3(BLOCK), 0, stream, R, S, C, sc, lane_spill(), P, Q, it0, it_end, seg_cap, refill, refill_connect, kinds_mask & 0x3fu, shade_cfg(it0), G, ticket(it0, TK_TAIL));
+        t1();
+        tail_at_last = it0;
+    }
+    void learn(const uint32_t *counts, uint32_t n_rows, uint32_t n_paths) { // counts[row * Q_STRIDE + q] of a finished pass
+        if (!n_paths || n_paths < 4096u) return; // (too few paths to speak for the scene)
+        std::vector<double> f(n_rows);
+        for (uint32_t i = 0; i < n_rows; ++i) f[i] = (double)counts[(size_t)i * Q_STRIDE + Q_EXT] / (double)n_paths;
+        ps->alive_frac.swap(f);
+    }
     void shade(uint32_t it, int kind) {
         t0(T_SHADE);
         if (kind > 5) kind = 5;
@@ -1538,13 +1671,13 @@ struct HipBackend {
         for (auto &s : spans) {
             float ms = 0.0f;
             if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-                if (s.cat == T_EXTEND) st.ms_extend += ms; else if (s.cat == T_CONNECT) st.ms_connect += ms; else if (s.cat == T_SHADE) st.ms_shade_kernels += ms; else if (s.cat == T_AUX) st.ms_aux += ms; else st.ms_film += ms;
+                if (s.cat == T_EXTEND) st.ms_extend += ms; else if (s.cat == T_CONNECT) st.ms_connect += ms; else if (s.cat == T_SHADE) st.ms_shade_kernels += ms; else if (s.cat == T_AUX) st.ms_aux += ms; else if (s.cat == T_TAIL) st.ms_tail += ms; else st.ms_film += ms;
             }
         }
         st.ms_trace = st.ms_extend + st.ms_connect; st.ms_shade = st.ms_shade_kernels + st.ms_aux;
         st.queue_segments = G; st.lanes = n_lanes; st.grid_pct = (uint64_t)(opt.grid_pct ? opt.grid_pct : 100);
         { const int cls[4] = {T_EXTEND, T_CONNECT, T_SHADE, T_AUX}; for (int k = 0; k < 4; ++k) { st.grid_wgs[k] = last_grid[cls[k]]; st.resident_wgs_per_cu[k] = last_per_cu[cls[k]]; } }
-        st.extend_launches = cat_launches[T_EXTEND]; st.connect_launches = cat_launches[T_CONNECT]; st.shade_launches = cat_launches[T_SHADE]; st.aux_launches = cat_launches[T_AUX]; st.film_launches = cat_launches[T_FILM];
+        st.extend_launches = cat_launches[T_EXTEND]; st.connect_launches = cat_launches[T_CONNECT]; st.shade_launches = cat_launches[T_SHADE]; st.aux_launches = cat_launches[T_AUX]; st.film_launches = cat_launches[T_FILM]; st.tail_launches = cat_launches[T_TAIL]; st.tail_round = tail_at_last;
         size_t bytes = 0;
         for (auto &l : ps->ws) for (auto &b : l) bytes += b.bytes;
         for (auto &b : ps->counts) bytes += b.bytes;

@@ -37,7 +37,7 @@ def load_library():
     L = C.CDLL(so)
     L.ptrs_last_error.restype = C.c_char_p
     L.ptrs_build_id.restype = C.c_char_p
-    if L.ptrs_abi_version() != 3:
+    if L.ptrs_abi_version() != 4:
         raise PtrsError("ABI version mismatch")
     structs = [abi.PtrsTexture, abi.PtrsMaterial, abi.PtrsMesh, abi.PtrsLight, abi.PtrsBvhNode, abi.PtrsSceneDesc, abi.PtrsCamera,
                abi.PtrsRenderParams, abi.PtrsStats, abi.PtrsHit]

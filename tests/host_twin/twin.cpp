@@ -137,6 +137,9 @@ struct HostBackend {
     void publish_rows(v4 *, int32_t, int32_t) {}
     void dump_rays(uint32_t, const RayDump &) {}
     void presample(uint32_t) {}
+    uint32_t tail_round(uint32_t, uint32_t) const { return 0xffffffffu; } // (the fused tail is a launch-shape matter of the gfx950 back end)
+    void tail(uint32_t, uint32_t) {}
+    void learn(const uint32_t *, uint32_t, uint32_t) {}
     void export_samples(float *out) {
         for (uint32_t pid = 0; pid < R.n_paths; ++pid) {
             PathCoord c = path_coord(R, S, pid);

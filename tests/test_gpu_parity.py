@@ -116,6 +116,8 @@ def _gpu_vs_oracle(ptrs, orc, cam, scene, spp, depth, **opts):
     st = integ.last_stats
     if "lanes" in opts:
         assert st.lanes == opts["lanes"]
+    if "tail_at" in opts:
+        assert st.tail_launches == st.passes and st.tail_round == opts["tail_at"], "the scene has no fused-tail instantiation"
     film_ref, ref, ost = orc.OracleScene(scene).render(cam, orc.make_params(cam.film.width, cam.film.height, spp, depth), n_threads=8, want_samples=True)
     assert (st.samples, st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.samples, ost.rays_extension, ost.rays_shadow, ost.rays_mis)
     bad = (samples.view(np.uint32) != ref.view(np.uint32)).any(axis=-1)
@@ -140,6 +142,34 @@ def test_shipped_four_lane_schedule_matches_oracle(ptrs, orc, scenes):
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15, lanes=4)
     cam, scene = scenes.material_zoo((120, 80))
     _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15, lanes=4)
+
+
+def test_fused_tail_matches_oracle(ptrs, orc, scenes):
+    """k_tail: from the hand-over round on every wave takes its queue segment through extend -> shade -> connect of ALL remaining
+    rounds in one launch.  Held against the oracle sample by sample for every form it is instantiated for: the LDS form (Cornell),
+    quad nodes out of global memory for a Matte scene (Cornell with node_form = 2) and for Disney + image textures (colonnade);
+    from round 0 (the whole pass in one launch), from a middle round, on one lane and on four; and placed by the scene's
+    learned survival profile (second render of a scene)."""
+    def run(cam, scene, spp, depth, **opts):
+        _gpu_vs_oracle(ptrs, orc, cam, scene, spp, depth, **opts)
+    for opts in ({"tail_at": 0}, {"tail_at": 2, "lanes": 4}, {"tail_at": 7}, {"tail_at": 1, "node_form": 2}):
+        cam, scene = ptrs.import_scene(CORNELL, (64, 64))  # (a fresh scene: node_form is read when the device scene is created, inside the render)
+        run(cam, scene, 8, 15, **opts)
+    # the learned placement: the first render of a scene runs round by round and leaves the profile, the second hands over where the
+    # profile says a segment holds at most tail_paths paths -- here, with 16 384 segments for 37 k paths, at round 0
+    cam, scene = ptrs.import_scene(CORNELL, (64, 64))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(8, cam.film.get_sample_bounds()), 15)
+    integ.render(cam, scene)
+    assert integ.last_stats.tail_launches == 0 and integ.last_stats.tail_round == 0xffffffff
+    cam.film.clear()
+    s2 = integ.render(cam, scene, want_samples=True)
+    st = integ.last_stats
+    assert st.tail_launches == st.passes and st.tail_round == 0
+    _, ref, _ = orc.OracleScene(scene).render(cam, orc.make_params(64, 64, 8, 15), n_threads=8, want_samples=True)
+    assert np.array_equal(s2.view(np.uint32), ref.view(np.uint32))
+    cam, scene = scenes.colonnade((160, 90))
+    run(cam, scene, 4, 15, tail_at=0)
+    run(cam, scene, 4, 15, tail_at=3, lanes=4)
 
 
 def test_triangle_soup_matches_oracle(ptrs, orc, scenes):
@@ -251,7 +281,8 @@ def test_launch_policy_options_do_not_change_the_film(ptrs):
     scenes_mod = __import__("importlib").import_module("pathtracer-rs_amd.scenes")
     cases = [(lambda: ptrs.import_scene(CORNELL, (96, 80)), 16, 8, 30000), (lambda: scenes_mod.material_zoo((72, 48)), 8, 15, 20000)]
     combos = [{}, {"lanes": 1}, {"lanes": 4, "grid_pct": 10}, {"grid_mult": 1, "persist": 0}, {"grid_mult": 64, "whole_rounds": 1}, {"lanes": 3, "grid_pct": 100, "grid_mult": 3},
-              {"lanes": 2, "fused_epilogue": 0, "grid_mult": 2}, {"lanes": 4, "node_form": 2}, {"lanes": 4, "node_form": 2, "grid_mult": 3}]  # (node_form 2: quad nodes with per-axis planes out of global memory)
+              {"lanes": 2, "fused_epilogue": 0, "grid_mult": 2}, {"lanes": 4, "node_form": 2}, {"lanes": 4, "node_form": 2, "grid_mult": 3},  # (node_form 2: quad nodes with per-axis planes out of global memory)
+              {"tail": 0}, {"tail_at": 0}, {"tail_at": 1, "lanes": 4}, {"tail_at": 3, "grid_mult": 2}, {"tail_at": 5, "lanes": 1}, {"tail_at": 2, "node_form": 2, "lanes": 4}]  # the fused tail from round k on (Cornell has an instantiation, the zoo -- every material kind -- has none: the knob is inert there)
     for scene_fn, spp, depth, ppp in cases:
         ref, st0 = film(scene_fn, combos[0], spp, depth, ppp)
         assert st0.passes >= 2 and st0.queue_segments > 0 and st0.lanes >= 1

@@ -21,4 +21,5 @@ for rows in (1, 4, 16, 64, 128, 256, 512, 1024):
         torch.cuda.synchronize(); t = time.perf_counter()
         st = integ.render_device(cam, scene, film.data_ptr(), stream=0, row_begin=448, row_end=448 + rows) if rows < 1024 else integ.render_device(cam, scene, film.data_ptr(), stream=0)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-    print("rows %4d: %7.2f ms (min of 3 after a warm-up; %5.1f ms per 128 rows), lanes %d, segments %d, passes %d" % (rows, min(ts[1:]) * 1e3, min(ts[1:]) * 1e3 * 128 / rows, st.lanes, st.queue_segments, st.passes))
+    print("rows %4d: %7.2f ms (min of 3 after a warm-up; %5.1f ms per 128 rows), lanes %d, segments %d, passes %d, launches %d, tail from round %s" % (
+        rows, min(ts[1:]) * 1e3, min(ts[1:]) * 1e3 * 128 / rows, st.lanes, st.queue_segments, st.passes, st.kernel_launches, st.tail_round if st.tail_launches else "-"))
