@@ -476,12 +476,17 @@ def main():
     standard = (spp, (W, H), args.depth, args.paths_per_pass) == (wl["spp"], wl["res"], DEPTH, 0)
     integ = pkg.PathIntegrator(pkg.SamplerBuilder(spp, cam.film.get_sample_bounds()), args.depth, device=local_rank, paths_per_pass=args.paths_per_pass)
     integ.preprocess(scene)
-    # N > 1: bands of equal cost (per-row ray counts of an untimed 1-spp probe; every rank computes the same plan), unless --even-bands
-    bounds, probe_ms = None, 0.0
+    # N > 1: bands of equal cost (per-row ray counts of ONE untimed 1-spp probe render with device counters; every rank computes the same
+    # plan), unless --even-bands or the plan would take less than 1 % off the slowest band
+    bounds, probe_ms, plan_gain = None, 0.0, None
     if world > 1 and not args.even_bands:
         tp = time.perf_counter()
-        bounds = par.plan_bands(H, world, par.probe_row_cost(pkg, cam, scene, args.depth, device=local_rank, strips=64, spp=1))
+        cost = par.probe_row_cost(pkg, cam, scene, args.depth, device=local_rank, spp=1)
         probe_ms = (time.perf_counter() - tp) * 1e3
+        plan_gain = par.plan_gain(H, world, cost)
+        if plan_gain >= 1.01:
+            bounds = par.plan_bands(H, world, cost)
+    if bounds is not None:
         row_b, row_e = bounds[rank], bounds[rank + 1]
     else:
         row_b, row_e = par.band_for_rank(H, rank, world)
@@ -626,7 +631,8 @@ def main():
             "dtype": "f32", "data": "synthetic (%s, deterministic Sobol sequence)" % ("data/cornell-box.xml as parsed" if args.workload == "cornell" else "procedural %s scene, seeded" % args.workload),
             "config": {"workload": wl["label"] % (W, H, spp, args.depth),
                        "msample_per_s": samples / dt / 1e6, "rays_per_sample": rays / max(samples, 1.0), "row_bands": world,
-                       "band_plan": ("single band" if world == 1 else ("equal height" if bounds is None else "equal cost (1-spp probe in 64 strips): rows %s" % (bounds,))),
+                       "band_plan": ("single band" if world == 1 else ("equal height" if bounds is None else "equal cost (one 1-spp probe render with a device counter per sample row): rows %s" % (bounds,))),
+                       "band_plan_gain_predicted": plan_gain,
                        "band_probe_ms": probe_ms, "value_incl_band_probe": rays / (dt + args.steps * probe_ms * 1e-3) / 1e6,  # a host that plans its bands per frame pays the probe per frame
                        "dist": {"backend": ("none" if world == 1 else ("rccl" if backend == "nccl" else backend + " (fallback or rehearsal: NOT an RCCL number)")), "world_size": dist.get_world_size() if world > 1 else 1,
                                 "launched_by": launched_by, "gather_mode": gather_mode if world > 1 else None, "gather_preflight": preflight,

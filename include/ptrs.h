@@ -294,6 +294,11 @@ int ptrs_render_progressive(PtrsScene *scene, const PtrsCamera *camera, const Pt
  * bands; ptrs_plan_bands computes them, optionally weighted by a per-row cost (row_cost[height], e.g. ray counts of
  * a 1-spp probe; NULL = equal rows).  stats_per_scene: n records or NULL.  Bit-identical to ptrs_render. */
 int ptrs_plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_t *bounds_out /* n + 1 */);
+/* The per-row cost for ptrs_plan_bands, measured: `params`' render (give spp = 1) with one device counter per sample row -- every BVH
+ * query a path makes is added to its row -- and no film; row_cost_out[height] = queries of the sample row under each output row.  One
+ * call of a few milliseconds; what it replaces is the reference's dynamic tile queue (integrator.rs:617-637), which balances at run
+ * time what a static band split has to know beforehand. */
+int ptrs_render_row_cost(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, float *row_cost_out, PtrsStats *stats);
 int ptrs_render_multi(PtrsScene *const *scenes, uint32_t n, const PtrsCamera *camera,
                       const PtrsRenderParams *params, const int32_t *band_bounds,
                       PtrsFilmPixel *film_inout, PtrsStats *stats_per_scene);

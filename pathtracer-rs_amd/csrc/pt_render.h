@@ -150,7 +150,8 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
                 const RenderProgress *progress = nullptr /* called after every pass with the rows it touched (back end copies them out first) */,
                 const RayDump *dump = nullptr,
                 const int32_t *single_pixel = nullptr /* render_single_pixel (integrator.rs:505-534): raster (px, py), any pixel of the sample bounds;
-                                                         traces that pixel's spp paths only, no film, samples_out = spp * 3 floats */) {
+                                                         traces that pixel's spp paths only, no film, samples_out = spp * 3 floats */,
+                uint32_t *row_cost = nullptr /* backend memory, NY counters (zeroed by the caller): the BVH queries of every sample row's paths are added; no film */) {
     using clock = std::chrono::steady_clock;
     const bool *kinds_present = sc_host_feat.kinds_present;
     auto t_begin = clock::now();
@@ -199,6 +200,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     R.NX = g.NX; R.NY = g.NY; R.W = prm.width; R.H = prm.height;
     R.inv_sqrt_spp = 1.0f / std::sqrt((float)g.spp);
     R.counters_on = (prm.flags & PTRS_FLAG_COUNTERS) ? 1u : 0u;
+    R.row_cost = row_cost;
 
     // ---- pass planning ----------------------------------------------------------------------
     // Passes run on `be.lanes()` independent pipelines (own path state, queues and stream): while one pass is in the thin
@@ -269,7 +271,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
             if (it == max_iters && be.read_count(it, Q_EXT) != 0) null_skip_overrun = true; // paths still alive: never dropped silently
         }
         pd.it = it;
-        if (pd.y1 > pd.y0) be.film(film, pd.y0, pd.y1); // ordered after the previous pass's film kernel, whichever lane ran it
+        if (pd.y1 > pd.y0 && film) be.film(film, pd.y0, pd.y1); // ordered after the previous pass's film kernel, whichever lane ran it
         if (samples_out) be.export_samples(samples_out);
         pd.open = false;
     };

@@ -175,6 +175,7 @@ struct DParams {
     uint32_t n_paths;      // (row1-row0)*NX*(s1-s0)
     uint32_t counters_on;
     int32_t pixel_mode, pix_sx, pix_sy; // render_single_pixel: the pass is the samples [s0,s1) of sample-pixel (pix_sx, pix_sy) and nothing else
+    uint32_t *row_cost;    // ptrs_render_row_cost: one counter per sample row of the grid (NY), + 1 for every BVH query a path of that row makes; null in a render
 };
 
 struct alignas(16) v4 { float x, y, z, w; };

@@ -435,6 +435,11 @@ __device__ inline void rf_step(const Geom &G, const DScene &sc, uint32_t &r_cur,
     }
 }
 
+__device__ inline uint32_t sample_row_of(const DParams &R, uint32_t pid) { // the row of the sample grid a path slot belongs to (path_coord's sy)
+    if (R.pixel_mode) return (uint32_t)R.pix_sy;
+    const uint32_t npix = (uint32_t)(R.row1 - R.row0) * (uint32_t)R.NX;
+    return (uint32_t)R.row0 + (pid % npix) / (uint32_t)R.NX;
+}
 template <int FEAT>
 __device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t kinds_mask, uint32_t seg_cap, uint32_t G, uint32_t s); // below, with k_epilogue
 template <int FEAT>
@@ -634,6 +639,7 @@ __device__ inline void epilogue_wave(const DParams &R, const DScene &sc, const D
         int k = -1; uint32_t pid = 0;
         if (i < n) {
             pid = pslot(Q.ext[par], e);
+            if (R.row_cost) atomicAdd(R.row_cost + sample_row_of(R, pid), 1u); // (band planning probe only: the extension ray this path traced this round)
             const u4 r = pslot(P.hit, e); // (the hits, the state words and the path slots of 64 consecutive positions: three coalesced reads)
             HitRec h; h.prim = hit_prim(r.x); h.t = 0.0f; h.b0 = u2f(r.y); h.b1 = u2f(r.z); h.b2 = u2f(r.w);
             h.flags = hit_flags(r.x); // the two fields of the leaf record's flags the epilogue reads
@@ -858,6 +864,7 @@ __device__ inline void shade_segment(const DParams &R, const DSampler &S, const 
 #endif
         c_shadow += (uint32_t)__popcll(__ballot(r.shadow));
         c_mis += (uint32_t)__popcll(__ballot(r.mis));
+        if (R.row_cost && (r.shadow || r.mis)) atomicAdd(R.row_cost + sample_row_of(R, m.pid), (r.shadow ? 1u : 0u) + (r.mis ? 1u : 0u)); // (band planning probe only)
         i = i2; m = m1; m1 = m2;
     }
     if (lane == 0) { // the wave is the segment's only writer in this launch
@@ -1263,13 +1270,13 @@ struct PtrsScene {
     // render workspace, grown on demand and reused across calls
     DevBuf ws[MAX_LANES][32];   // per pipeline lane
     DevBuf counts[MAX_LANES], totals[MAX_LANES], tickets[MAX_LANES];
-    DevBuf stats, table, film_tmp, samples_tmp, strat1, strat2;
+    DevBuf stats, table, film_tmp, samples_tmp, strat1, strat2, row_cost;
     hipStream_t lane_stream[MAX_LANES] = {}; // lane 0 runs on the caller's stream, the others on these
     hipEvent_t lane_ev[MAX_LANES] = {};      // film-done per lane
     std::vector<hipEvent_t> ev_pool;
     int n_cu = 256;
     ~PtrsScene() {
-        for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &stats, &table, &film_tmp, &samples_tmp, &strat1, &strat2}) b->release();
+        for (auto &b : {&stack_spill, &nodes2, &nodes4, &nodes, &tris, &shade, &mats, &texs, &levels, &texdata, &lights, &distdata, &inf, &stats, &table, &film_tmp, &samples_tmp, &strat1, &strat2, &row_cost}) b->release();
         for (auto &b : counts) b.release();
         for (auto &b : totals) b.release();
         for (auto &b : tickets) b.release();
@@ -1692,8 +1699,8 @@ Options scene_options(const PtrsScene *ps) { // the process-wide knobs with this
 }
 
 int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm, v4 *film_dev, float *samples_dev, hipStream_t stream, PtrsStats *stats, const int32_t *single_pixel = nullptr,
-              const RenderProgress *progress = nullptr, PtrsFilmPixel *host_film = nullptr, int share = 1, const RayDump *dump = nullptr) {
-    if (!ps || !cam || !prm || (!film_dev && !single_pixel)) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+              const RenderProgress *progress = nullptr, PtrsFilmPixel *host_film = nullptr, int share = 1, const RayDump *dump = nullptr, uint32_t *row_cost_dev = nullptr) {
+    if (!ps || !cam || !prm || (!film_dev && !single_pixel && !row_cost_dev)) { g_err = "null argument"; return PTRS_ERR_INVALID; }
     HIPCHK(hipSetDevice(ps->device));
     HipBackend be;
     be.ps = ps; be.stream = stream; be.opt = scene_options(ps); be.host_film = host_film; be.film_w = prm->width; be.share = share;
@@ -1701,7 +1708,7 @@ int do_render(PtrsScene *ps, const PtrsCamera *cam, const PtrsRenderParams *prm,
     int rc = get_sobol(ps->device, &be.sob);
     if (rc != PTRS_OK) return rc;
     std::string err;
-    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err, progress, dump, single_pixel);
+    rc = render_impl(be, ps->sc, ps->H, ps->H.max_depth, *cam, *prm, film_dev, samples_dev, stats, err, progress, dump, single_pixel, row_cost_dev);
     if (rc != PTRS_OK) { if (!err.empty()) g_err = err; return rc; }
     if (be.rc != PTRS_OK) { if (g_err.empty()) g_err = "device error during render"; return be.rc; }
     return PTRS_OK;
@@ -1877,6 +1884,30 @@ int ptrs_render_progressive(PtrsScene *scene, const PtrsCamera *camera, const Pt
 int ptrs_plan_bands(int32_t height, uint32_t n, const float *row_cost, int32_t *bounds_out) {
     if (height <= 0 || n == 0 || !bounds_out) { g_err = "bad band request"; return PTRS_ERR_INVALID; }
     return guarded([&]() -> int { plan_bands(height, n, row_cost, bounds_out); return PTRS_OK; });
+}
+
+// Band planning probe: `params`' render (the caller gives spp = 1) with one counter per sample row on the device -- every BVH
+// query (extension, shadow, MIS ray) of a path is added to its row when the stage that issues it runs -- and no film.  One call of a few
+// milliseconds where the planner of round 3 made 64 strip renders (270 ms for Cornell).  row_cost_out[y], y in [0, height): the queries of
+// the sample row under output row y (grid row y + 2); the apron's rows are left out.
+int ptrs_render_row_cost(PtrsScene *scene, const PtrsCamera *camera, const PtrsRenderParams *params, float *row_cost_out, PtrsStats *stats) {
+    return guarded([&]() -> int {
+        if (!scene || !camera || !params || !row_cost_out) { g_err = "null argument"; return PTRS_ERR_INVALID; }
+        if (params->width <= 0 || params->height <= 0) { g_err = "bad render parameters"; return PTRS_ERR_INVALID; }
+        HIPCHK(hipSetDevice(scene->device));
+        const SampleGrid g = make_sample_grid(params->width, params->height, params->spp);
+        int rc = scene->row_cost.ensure((size_t)g.NY * 4);
+        if (rc != PTRS_OK) return rc;
+        HIPCHK(hipMemset(scene->row_cost.p, 0, (size_t)g.NY * 4));
+        PtrsRenderParams p = *params;
+        p.row_begin = 0; p.row_end = p.height;
+        rc = do_render(scene, camera, &p, nullptr, nullptr, nullptr, stats, nullptr, nullptr, nullptr, 1, nullptr, (uint32_t *)scene->row_cost.p);
+        if (rc != PTRS_OK) return rc;
+        std::vector<uint32_t> h((size_t)g.NY);
+        HIPCHK(hipMemcpy(h.data(), scene->row_cost.p, (size_t)g.NY * 4, hipMemcpyDeviceToHost));
+        for (int32_t y = 0; y < params->height; ++y) row_cost_out[y] = (float)h[(size_t)(y - g.min_y)];
+        return PTRS_OK;
+    });
 }
 
 int ptrs_scene_set_option(PtrsScene *scene, const char *name, int64_t value) {

@@ -116,21 +116,12 @@ int PathIntegrator::render(Camera &camera, RenderScene &scene, PtrsStats *stats)
     return rc;
 }
 
-bool probe_row_cost(PtrsScene *scene, const PtrsCamera &camera, const PtrsRenderParams &params, int strips, std::vector<float> &row_cost, std::string &err) {
-    const int H = params.height;
-    strips = std::max(1, std::min(strips, H));
-    row_cost.assign((size_t)H, 0.0f);
-    std::vector<PtrsFilmPixel> scratch((size_t)params.width * (size_t)H, PtrsFilmPixel{{0, 0, 0}, 0});
+bool probe_row_cost(PtrsScene *scene, const PtrsCamera &camera, const PtrsRenderParams &params, int /* strips: the old form's; ignored */, std::vector<float> &row_cost, std::string &err) {
+    row_cost.assign((size_t)params.height, 0.0f);
     PtrsRenderParams p = params;
     p.spp = 1;
-    for (int k = 0; k < strips; ++k) {
-        p.row_begin = (int)((long long)H * k / strips); p.row_end = (int)((long long)H * (k + 1) / strips);
-        if (p.row_end <= p.row_begin) continue;
-        PtrsStats st{};
-        if (ptrs_render(scene, &camera, &p, scratch.data(), &st) != PTRS_OK) { err = ptrs_last_error(); return false; }
-        const float per_row = (float)((double)(st.rays_extension + st.rays_shadow + st.rays_mis) / (double)(p.row_end - p.row_begin));
-        for (int y = p.row_begin; y < p.row_end; ++y) row_cost[(size_t)y] = per_row;
-    }
+    PtrsStats st{};
+    if (ptrs_render_row_cost(scene, &camera, &p, row_cost.data(), &st) != PTRS_OK) { err = ptrs_last_error(); return false; } // one 1-spp render with a device counter per sample row
     return true;
 }
 
@@ -143,14 +134,26 @@ int PathIntegrator::render_multi(Camera &camera, RenderScene &scene, int n_devic
             int rc = ptrs_scene_create(&scene.desc(), d, &multi_scenes_[(size_t)d]);
             if (rc != PTRS_OK) { last_error = std::string("device ") + std::to_string(d) + ": " + ptrs_last_error(); return rc; }
         }
-        multi_src_ = &scene;
+        multi_src_ = &scene; plan_key_.clear();
     }
     const PtrsRenderParams p = params(camera);
     std::vector<int32_t> bounds((size_t)n_devices + 1);
     std::vector<float> cost;
-    if (cost_weighted && n_devices > 1 && !probe_row_cost(multi_scenes_[0], camera.abi, p, 64, cost, last_error)) return PTRS_ERR_DEVICE;
-    int rc = ptrs_plan_bands(p.height, (uint32_t)n_devices, cost.empty() ? nullptr : cost.data(), bounds.data());
-    if (rc != PTRS_OK) { last_error = ptrs_last_error(); return rc; }
+    int rc = PTRS_OK;
+    if (cost_weighted && n_devices > 1) {
+        // the plan of a view is made once: a second frame of the same scene, camera, resolution and depth on the same devices pays nothing
+        std::string key((const char *)&camera.abi, sizeof(camera.abi));
+        key.append((const char *)&p.width, sizeof(p.width)).append((const char *)&p.height, sizeof(p.height)).append((const char *)&p.max_depth, sizeof(p.max_depth)).append((const char *)&n_devices, sizeof(n_devices));
+        if (key != plan_key_) {
+            if (!probe_row_cost(multi_scenes_[0], camera.abi, p, 0, cost, last_error)) return PTRS_ERR_DEVICE;
+            std::vector<int32_t> planned((size_t)n_devices + 1), even((size_t)n_devices + 1);
+            if ((rc = ptrs_plan_bands(p.height, (uint32_t)n_devices, cost.data(), planned.data())) != PTRS_OK || (rc = ptrs_plan_bands(p.height, (uint32_t)n_devices, nullptr, even.data())) != PTRS_OK) { last_error = ptrs_last_error(); return rc; }
+            auto worst = [&](const std::vector<int32_t> &b) { double w = 0.0; for (int d = 0; d < n_devices; ++d) { double c = 0.0; for (int32_t y = b[(size_t)d]; y < b[(size_t)d + 1]; ++y) c += cost[(size_t)y]; w = std::max(w, c); } return w; };
+            plan_ = worst(even) > 1.01 * worst(planned) ? planned : even; // equal bands unless the plan takes at least 1 % off the slowest band
+            plan_key_ = key;
+        }
+        bounds = plan_;
+    } else if ((rc = ptrs_plan_bands(p.height, (uint32_t)n_devices, nullptr, bounds.data())) != PTRS_OK) { last_error = ptrs_last_error(); return rc; }
     if (bands_out) *bands_out = bounds;
     rc = ptrs_render_multi(multi_scenes_.data(), (uint32_t)n_devices, &camera.abi, &p, bounds.data(), camera.film.pixels.data(), stats);
     if (rc != PTRS_OK) last_error = ptrs_last_error();

@@ -98,7 +98,7 @@ public:
     std::function<void(uint32_t, uint32_t, int32_t, int32_t)> on_pass;
     // The same render split over the devices 0 .. n_devices-1 of this process: the scene is uploaded to every
     // device, output rows are cut into one band per device -- weighted by the ray counts of a 1-spp probe when
-    // cost_weighted -- and ptrs_render_multi renders the bands on one host thread per device and gathers them.  The film
+    // cost_weighted and the plan takes at least 1 % off the slowest band; planned once per view -- and ptrs_render_multi renders the bands on one host thread per device and gathers them.  The film
     // is bit-identical to render()'s.  stats: n_devices records or nullptr; bands_out: n_devices + 1 row bounds.
     int render_multi(Camera &camera, RenderScene &scene, int n_devices, bool cost_weighted = true, PtrsStats *stats = nullptr, std::vector<int32_t> *bands_out = nullptr);
     std::string last_error;
@@ -115,11 +115,13 @@ private:
     const RenderScene *gpu_scene_src_ = nullptr;
     std::vector<PtrsScene *> multi_scenes_; // one per device, device i at index i
     const RenderScene *multi_src_ = nullptr;
+    std::string plan_key_;          // the view (camera, resolution, depth, device count) plan_ was made for
+    std::vector<int32_t> plan_;     // its row bounds
     PtrsRenderParams params(const Camera &camera) const;
 };
 
-// Per-row cost of a frame for band planning: ray counts of a 1-spp render of `strips` horizontal strips on `scene`
-// (a probe: milliseconds), spread evenly over each strip's rows.  Returns false and fills err on failure.
+// Per-row cost of a frame for band planning: the BVH queries of every sample row's paths in ONE 1-spp render with device counters
+// (ptrs_render_row_cost: a few milliseconds).  Returns false and fills err on failure.
 bool probe_row_cost(PtrsScene *scene, const PtrsCamera &camera, const PtrsRenderParams &params, int strips, std::vector<float> &row_cost, std::string &err);
 
 // importer::import for Mitsuba XML (rectangle / cube shapes, twosided / diffuse / conductor /
