@@ -480,9 +480,10 @@ def main():
     # plan), unless --even-bands or the plan would take less than 1 % off the slowest band
     bounds, probe_ms, plan_gain = None, 0.0, None
     if world > 1 and not args.even_bands:
-        tp = time.perf_counter()
-        cost = par.probe_row_cost(pkg, cam, scene, args.depth, device=local_rank, spp=1)
-        probe_ms = (time.perf_counter() - tp) * 1e3
+        cost = par.probe_row_cost(pkg, cam, scene, args.depth, device=local_rank, spp=1)  # (the process's first call into the library: scene upload and workspace allocation ride on it)
+        torch.cuda.synchronize(); tp = time.perf_counter()
+        par.probe_row_cost(pkg, cam, scene, args.depth, device=local_rank, spp=1, cache=False)  # what the probe itself costs (a host that plans a NEW view pays this once; the same view again comes out of the cache)
+        torch.cuda.synchronize(); probe_ms = (time.perf_counter() - tp) * 1e3
         plan_gain = par.plan_gain(H, world, cost)
         if plan_gain >= 1.01:
             bounds = par.plan_bands(H, world, cost)
