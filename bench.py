@@ -56,6 +56,7 @@ SIMDS, CUS = 1024.0, 256.0
 CLASS_B_CYCLES = 4.2                       # profiles/r03_valu_ceiling.json: one comparison / select / min-max class instruction per 4.2 cycles and SIMD; fp32 add / mul / fma issue beside them
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_%s.json")
 CEILING_FILE = os.path.join(ROOT, "profiles", "r03_valu_ceiling.json")
+CALIB_FILE = os.path.join(ROOT, "profiles", "r04_fetch_calib.json")
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_%s_rows.npz")
 
 
@@ -405,8 +406,17 @@ def trace_main(args):
         roof["traffic"] = pmc["hbm_bytes"] / max(launches, 1)
         roof["achieved"] = pmc["hbm_gbs"]; roof["frac"] = pmc["hbm_counter_frac_of_8TBs"]; roof["l2_hit_rate"] = pmc["l2_hit_rate"]
         roof["bound"] = pmc.get("bound")
-        roof["what"] = "FETCH_SIZE + WRITE_SIZE of the profiled launches (secondary-ray set) / their duration against the 8 TB/s HBM peak: the HBM-read roofline fraction of traversal north_star sets >= 40 % for -- it is NOT met, the kernel waits for L2 / HBM latency at 4-5 waves per SIMD instead of streaming"
-        roof["fetch_size_note"] = "FETCH_SIZE as rocprofv3 reports it, not doubled: the gfx950 x2 correction is calibrated for 16 B/lane streaming reads, these are 16-byte gathers of 128-byte records"
+        roof["what"] = ("2 x FETCH_SIZE + WRITE_SIZE of the profiled launches (secondary-ray set) / their duration against the 8 TB/s HBM peak.  These are the bytes that crossed the fabric below L2 -- "
+                        "HBM AND Infinity Cache: the counter cannot tell them apart (profiles/r04_fetch_calib.json) and this tree (tens of MB) fits the 256 MiB Infinity Cache, so the HBM share is smaller still.  "
+                        "north_star's '>= 40 % of the HBM-read roofline during traversal' is therefore not evaluable as HBM on a BASELINE-sized scene; as memory-side bytes the kernel is just under it, and it is bound "
+                        "by neither bandwidth: a dependent walk over random 128-byte records at this occupancy (calibration kernel) moves `random_record_walk_ceiling_gbs`, this kernel -- which computes four slab tests per record -- `achieved`")
+        roof["fetch_size_note"] = "FETCH_SIZE x 2: calibrated on this access shape (tools/fetch_calib.hip): FETCH_SIZE = TCC_MISS x 64 B exactly, for 16 B/lane streams and for gathers of 128-byte records, Infinity-Cache-resident or not"
+        roof["l2_miss_bytes_per_launch"] = (pmc.get("l2_miss_bytes") or 0.0) / max(launches, 1)
+        if os.path.exists(CALIB_FILE):
+            cj = json.load(open(CALIB_FILE))
+            roof["random_record_walk_ceiling_gbs"] = {"infinity_cache_resident_table_64MB": cj["gather_64MB_dependent"]["record_visits_per_s"] * 128.0 / 1e9, "hbm_resident_table_2GB": cj["gather_2GB_dependent"]["record_visits_per_s"] * 128.0 / 1e9,
+                                                      "streaming_read_2GB": cj["stream_2GB"]["gbs"], "what": "tools/fetch_calib.hip at 5 waves per SIMD: dependent visits of random 128-byte records x 128 B; a 16 B/lane stream"}
+            roof["frac_of_random_record_walk_ceiling"] = (roof["achieved"] or 0.0) / roof["random_record_walk_ceiling_gbs"]["infinity_cache_resident_table_64MB"]
         roof["counters"] = {k: pmc.get(k) for k in ("valu_pipe_frac_lo", "valu_pipe_frac_hi", "wave_issue_frac", "wave_wait_frac", "wave_stall_frac", "waves_resident_per_simd", "lanes_per_valu_inst", "salu_per_valu", "calls")}
         roof["counters_from"] = os.path.relpath(pmc_path, ROOT)
     out = {"metric": "Mray/s, traversal only, %s (%d triangles), secondary rays of a %dx%d frame at depth 3" % (name, scene.num_triangles(), res[0], res[1]),
@@ -601,7 +611,7 @@ def main():
             "wave": {"issue": d.get("wave_issue_frac"), "wait": d.get("wave_wait_frac"), "stall": d.get("wave_stall_frac"), "salu_per_valu": d.get("salu_per_valu"), "lanes_per_valu_inst": d.get("lanes_per_valu_inst"),
                      "lds_busy": d.get("lds_busy_frac"), "lds_conflict_share": d.get("lds_conflict_share")},
             "traffic": d.get("hbm_bytes_per_launch"),
-            "hbm": {"achieved": d.get("hbm_counter_gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d.get("hbm_counter_frac"), "what": "FETCH_SIZE + WRITE_SIZE of the class's kernels (committed rocprofv3 PMC passes) / their single-lane duration measured in this run"},
+            "hbm": {"achieved": d.get("hbm_counter_gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d.get("hbm_counter_frac"), "what": "2 x FETCH_SIZE + WRITE_SIZE of the class's kernels (committed rocprofv3 PMC passes; FETCH_SIZE calibrated: profiles/r04_fetch_calib.json) / their single-lane duration measured in this run: bytes below L2 (HBM + Infinity Cache)"},
             "algorithmic": {"what": "SURVEY 8(d): 32 B ray in + 32 B per box tested + 48 B per triangle tested + 16 B hit out, x rays / traversal-kernel time; NOT HBM traffic (LDS- and L2-served)",
                             "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray, "gbs": classes["traversal"].get("algorithmic_gbs"), "frac_of_hbm_peak": classes["traversal"].get("algorithmic_frac_of_hbm_peak"),
                             "bytes_per_launch": xst.rays * b_ray / max(xst.extend_launches + xst.connect_launches, 1)},

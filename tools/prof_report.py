@@ -3,8 +3,11 @@
 
     python tools/prof_report.py gpurun_out/prof_TAG [--json OUT.json] [--frames N] [--workload W]
 
-Units (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (FETCH_SIZE is NOT doubled here: the gfx950
-x2 correction is calibrated for 16 B/lane streaming reads only, these kernels gather); SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*
+Units (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them.  FETCH_SIZE IS DOUBLED here: calibrated on this
+library's own access shapes (tools/fetch_calib.hip -> profiles/r04_fetch_calib.json) it reports exactly half of TCC_MISS x 128 B --
+for 16 B/lane streams and for the traversal's gathers of 128-byte records alike, for tables in HBM and for tables that live in the
+Infinity Cache alike: it counts the L2's memory-side read requests (128 B tallied as 64), Infinity-Cache hits included.  `hbm_bytes`
+is therefore what crossed the fabric below L2 (HBM + Infinity Cache), an UPPER bound of the HBM bytes; SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_*
 in quad-cycles summed over waves; SQ_BUSY_CYCLES summed over the 32 shader engines; GRBM_GUI_ACTIVE summed over the 8 XCDs.
 
 Every fraction printed here is bounded by 1 by construction:
@@ -55,7 +58,8 @@ def digest(k):
             continue
         g = lambda c: v.get(c, 0.0)
         cyc = g("GRBM_GUI_ACTIVE") / 8.0  # cycles the kernel's dispatches were in flight (profiled run)
-        hbm = (g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
+        fetch = 2.0 * g("FETCH_SIZE") * 1024.0  # calibrated (profiles/r04_fetch_calib.json): FETCH_SIZE = 1/2 x TCC_MISS x 128 B for streams and gathers alike
+        hbm = fetch + g("WRITE_SIZE") * 1024.0
         nv = g("SQ_INSTS_VALU")
         fp32 = g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_FMA_F32")
         ints = g("SQ_INSTS_VALU_INT32") + g("SQ_INSTS_VALU_INT64")
@@ -68,7 +72,8 @@ def digest(k):
         lds_active = g("SQ_LDS_IDX_ACTIVE")
         o = {
             "calls": v["calls"], "total_ms": v["total_ms"], "avg_ms": v["avg_ms"], "pct_of_gpu_time": v["pct"],
-            "hbm_bytes": hbm, "hbm_bytes_per_launch": hbm / max(v["calls"], 1), "hbm_gbs": hbm / (v["total_ms"] * 1e-3) / 1e9 if v["total_ms"] else 0.0,
+            "hbm_bytes": hbm, "fetch_bytes_calibrated": fetch, "write_bytes": g("WRITE_SIZE") * 1024.0, "l2_miss_bytes": g("TCC_MISS_sum") * 128.0, "fetch_size_factor": 2.0,
+            "hbm_bytes_per_launch": hbm / max(v["calls"], 1), "hbm_gbs": hbm / (v["total_ms"] * 1e-3) / 1e9 if v["total_ms"] else 0.0,
             "hbm_counter_frac_of_8TBs": hbm / (v["total_ms"] * 1e-3) / 8e12 if v["total_ms"] else 0.0,
             "lanes_per_valu_inst": g("SQ_THREAD_CYCLES_VALU") / max(nv, 1.0),
             "valu_insts": nv, "valu_fp32_add_mul_fma": fp32, "valu_int": ints, "valu_trans": g("SQ_INSTS_VALU_TRANS_F32"), "valu_cvt": g("SQ_INSTS_VALU_CVT"),
@@ -115,7 +120,7 @@ def main():
             src = "?"
         dg["_meta"] = {"frames": int(arg("--frames", "1")), "workload": arg("--workload", "?"), "source_hash": src,
                        "command": "tools/prof.sh: rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --workload W --steps FRAMES --profile` (one pipeline lane)",
-                       "units": "hbm_bytes = (FETCH_SIZE + WRITE_SIZE) KiB x 1024 as reported (FETCH_SIZE not doubled: 16-byte gathers, uncalibrated); fractions and their bounds: tools/prof_report.py"}
+                       "units": "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: FETCH_SIZE calibrated on this library's access shapes (profiles/r04_fetch_calib.json: exactly half of TCC_MISS x 128 B for streams and for gathers of 128-byte records, Infinity-Cache hits included) -- bytes below L2 (HBM + Infinity Cache), an upper bound of HBM bytes; fractions and their bounds: tools/prof_report.py"}
         json.dump(dg, open(arg("--json", "pmc.json"), "w"), indent=1, sort_keys=True)
         dg.pop("_meta")
     f = lambda x: "  -  " if x is None else "%5.2f" % x
