@@ -460,11 +460,27 @@ __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQu
 template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? PTRS_LDS_WAVES : ((GEOM == 0 && DEPTH == 8) ? PTRS_QUAD_WAVES : 0) }; };
 template <int DEPTH, int GEOM> struct TravLds { enum { TOP = GEOM == 0 && DEPTH == 8, V4 = GEOM > 0 ? GEOM : (TOP ? TOP_LDS_STRIDE * QUAD_TOP_NODES : 1) }; }; // quad form with the small stack column: the tree's top lives in LDS
 
+// Diagnostic builds only (-DPTRS_STAMPS_EXT, tools/ablate.sh + tools/stamps_ext.py): wave clocks of the phases of the extension stage, summed
+// into Q.stats[CNT_STAMP0 + k] -- 0 retire + bookkeeping, 1 refill (ray loads until the rays are set up), 2 traversal steps, 3 epilogue,
+// 4 tickets + segment count, 5 kernel prologue (tables into LDS) -- and counts: 6 wave-steps, 7 refill batches, 8 rays, 9 lanes with a ray
+// summed over the wave-steps, 10 segments, 11 lanes at a NODE summed over the wave-steps.  A stamp drains the wave's memory operations first,
+// so a phase owns its own latencies.  The product build compiles none of it.
+#ifdef PTRS_STAMPS_EXT
+#define PT_XS_PARAMS , unsigned long long *xs, unsigned long long &xs_last
+#define PT_XS_ARGS , xs, xs_last
+#define PT_XS(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); xs[k] += t_ - xs_last; xs_last = t_; }
+#define PT_XS_COUNT(k, v) { xs[k] += (unsigned long long)(v); }
+#else
+#define PT_XS_PARAMS
+#define PT_XS_ARGS
+#define PT_XS(k)
+#define PT_XS_COUNT(k, v)
+#endif
 // One queue segment through the extension stage: the wave's refill loop, then (kinds_mask != 0) the segment's epilogue.  Called by
 // k_extend_rf for every segment the wave takes and by k_tail for its segment's remaining rounds.
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
 __device__ inline void extend_segment(const DParams &R, const DScene &sc, const DPaths &P, const DQueues &Q, uint32_t it, uint32_t seg_cap, uint32_t thresh, uint32_t kinds_mask, uint32_t Gn, uint32_t s,
-                                      const GeomTop &GG, const LdsGeom &LG, LdsStack<DEPTH, OVF> &stk, uint32_t &nn, uint32_t &nt, StepCount &stepc) {
+                                      const GeomTop &GG, const LdsGeom &LG, LdsStack<DEPTH, OVF> &stk, uint32_t &nn, uint32_t &nt, StepCount &stepc PT_XS_PARAMS) {
     const uint32_t e0 = s * seg_cap, par = it & 1u; // the segment's rays sit at positions e0 .. e0 + n of the round's ray arrays, in queue order: a refill is one coalesced read, no path slot is looked up
     const uint32_t n = rfl(*seg_count(Q, it, Q_EXT, Gn, s));
     uint32_t cursor = 0; // next entry of the segment: wave-uniform, a scalar register
@@ -479,7 +495,9 @@ __device__ inline void extend_segment(const DParams &R, const DScene &sc, const 
         }
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
+        PT_XS(0)
         if (cursor < n && n_idle >= thresh) {
+            PT_XS_COUNT(7, 1) PT_XS_COUNT(8, (n - cursor < n_idle ? n - cursor : n_idle))
             const uint32_t i = cursor + lanes_below(idle);
             if (!has && i < n) {
                 e = e0 + i;
@@ -488,20 +506,25 @@ __device__ inline void extend_segment(const DParams &R, const DScene &sc, const 
                 stk.clear(); has = true;
             }
             cursor += n_idle;
+            PT_XS(1)
         }
         if (!__any(has)) break; // every ray of the segment is retired
-        do { // steps until enough lanes are through their rays: only then is there something to retire or refill
+        do {
+            PT_XS_COUNT(6, 1) PT_XS_COUNT(9, __popcll(__ballot(has && r_cur != REF_NONE))) PT_XS_COUNT(11, __popcll(__ballot(has && (int32_t)r_cur >= 0))) // steps until enough lanes are through their rays: only then is there something to retire or refill
             if (GEOM > 0) lf_step<VOTE, (FEAT & FEAT_ALPHA) != 0>(sc, r_cur, l_o, l_inv, l_op, l_sx, l_sy, l_sz, l_ox, l_oy, l_oz, l_neg, l_tri, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
             else rf_step<VOTE, true, (FEAT & FEAT_ALPHA) != 0>(GG, sc, r_cur, r_o, r_inv, r_neg, r_nb3, r_px, r_py, r_pz, r_shear, r_tmax, r_h, r_hit, stk, nn, nt, false, stepc);
         // with phase voting the wave goes back to retiring / refilling only when that pays: enough lanes are through their rays
         // (or never had one) to reach the refill threshold, or no lane has a step left.  (Going back for every single ray costs
         // a store instruction and the refill bookkeeping per ray: more than the steps saved.)
         } while (VOTE && __any(has && r_cur != REF_NONE) && (cursor >= n || (uint32_t)__popcll(__ballot(!has || r_cur == REF_NONE)) < thresh));
+        PT_XS(2)
     }
     // The segment's epilogue runs here, behind the wave's last ray, unless kinds_mask = 0 leaves it to k_epilogue: the hits it
     // reads were written a moment ago by this wave (L2), and its memory latency hides behind the other waves' traversal
     // instead of filling a kernel of its own.  (The fence orders this wave's hit stores before the loads of other lanes.)
+    PT_XS(0)
     if (kinds_mask) { __threadfence_block(); epilogue_wave<FEAT>(R, sc, P, Q, it, kinds_mask, seg_cap, Gn, s); }
+    PT_XS(3) PT_XS_COUNT(10, 1)
 }
 
 template <int FEAT, int DEPTH, bool OVF, int GEOM, bool VOTE>
@@ -515,7 +538,14 @@ __global__ __launch_bounds__(BLOCK, (TravWaves<FEAT, DEPTH, GEOM>::N)) void k_ex
     __syncthreads(); // the only barrier of the kernel: from here on the four waves of the workgroup are independent
     LdsStack<DEPTH, OVF> stk; stk.init(lds_stack, spill);
     uint32_t nn = 0, nt = 0; StepCount stepc;
+#ifdef PTRS_STAMPS_EXT
+    unsigned long long xs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, xs_last = __builtin_amdgcn_s_memtime();
+    for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) { PT_XS(4) extend_segment<FEAT, DEPTH, OVF, GEOM, VOTE>(R, sc, P, Q, it, seg_cap, thresh, kinds_mask, Gn, s, GG, LG, stk, nn, nt, stepc PT_XS_ARGS); }
+    PT_XS(4)
+    if ((threadIdx.x & 63u) == 0) for (int k = 0; k < 12; ++k) atomicAdd(&Q.stats[CNT_STAMP0 + k], xs[k]);
+#else
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) extend_segment<FEAT, DEPTH, OVF, GEOM, VOTE>(R, sc, P, Q, it, seg_cap, thresh, kinds_mask, Gn, s, GG, LG, stk, nn, nt, stepc);
+#endif
     if (R.counters_on) { atomicAdd(&Q.stats[CNT_NODES], (unsigned long long)nn); atomicAdd(&Q.stats[CNT_TRIS], (unsigned long long)nt); atomicAdd(&Q.stats[CNT_NODE_STEPS], (unsigned long long)stepc.node_steps); atomicAdd(&Q.stats[CNT_NODE_VISITS], (unsigned long long)stepc.node_visits); atomicAdd(&Q.stats[CNT_TRI_STEPS], (unsigned long long)stepc.tri_steps); }
 }
 
@@ -941,7 +971,11 @@ __global__ __launch_bounds__(BLOCK, 2) void k_tail(DParams R, DSampler S, DCamer
     for (uint32_t s = seg_next(ticket, Gn); s < Gn; s = seg_next(ticket, Gn)) {
         for (uint32_t it = it0; it < it_end; ++it) {
             if (rfl(*(volatile uint32_t *)seg_count(Q, it, Q_EXT, Gn, s)) == 0u) break; // nobody of this segment reached the round
+#ifdef PTRS_STAMPS_EXT
+            { unsigned long long xs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, xs_last = 0; extend_segment<FEAT_T, DEPTH, OVF, GEOM, true>(R, sc, P, Q, it, seg_cap, thresh_e, kinds_mask, Gn, s, GG, LG, stk, nn, nt, stepc PT_XS_ARGS); }
+#else
             extend_segment<FEAT_T, DEPTH, OVF, GEOM, true>(R, sc, P, Q, it, seg_cap, thresh_e, kinds_mask, Gn, s, GG, LG, stk, nn, nt, stepc);
+#endif
             __threadfence_block();
 #ifdef PTRS_STAMPS
             shade_segment<MAT, FEAT, false>(R, S, C, sc, P, Q, it, seg_cap, Gn, s, X, lds_pf, err_dim, stamp_acc, stamp_last);
@@ -1309,25 +1343,30 @@ struct HipBackend {
     // one lane: 192), colonnade 114.9 (one lane with 16 384 segments: 116.9), classroom 847-852 (852); five and more lanes are
     // slower (182 / 174 / 167 ms for 5 / 6 / 8 on Cornell: the runtime maps streams onto four hardware queues).  A job too small to
     // give four lanes a pass each runs on one lane with 16 384 segments, and so does every single-lane render (the profiled frames).
-    uint32_t lanes(uint64_t job_paths = 0, const bool * = nullptr) {
+    uint32_t lanes(uint64_t job_paths = 0, const bool * = nullptr, bool single_pixel = false) {
         int want = opt.lanes;
-        if (want == 0) want = job_paths >= (4ull << 20) ? 4 : 1;
+        if (want == 0) want = (job_paths >= (4ull << 20) && !single_pixel) ? 4 : 1; // (render_single_pixel traces spp paths: one lane, the whole workspace)
+        if (share > 1 && opt.lanes == 0) want = std::max(1, want / share);        // renders that share a device (ptrs_render_multi replicas) share its hardware queues too
         n_lanes = (uint32_t)(want < 1 ? 1 : (want > MAX_LANES ? MAX_LANES : want));
+        return n_lanes;
+    }
+    // Segments per pass, once the passes are planned (begin(): `max_paths` is the size of the largest pass, whatever auto_capacity,
+    // paths_per_pass or the row-chunk plan made of the job).  Defaults: CUs x 8 with several lanes, CUs x 64 with one.
+    // Scenes whose tree lives in HBM / L2 (quad form) wait for node fetches and gain from more waves of a kernel in flight once a
+    // segment still holds ~10 k paths: classroom (66 M paths per pass) 801 -> 797 / 784 / 795 ms at 4 096 / 6 144 / 8 192 segments,
+    // colonnade (15 M per pass) 107.3 -> 110.2 / 112.9 / 115.9: it stays at 2 048.  (The LDS-resident Cornell, bound by what the
+    // SIMDs issue, loses 1 % at 4 096.)
+    void plan_segments(uint64_t max_paths) {
         if (opt.grid_mult == 0) {
             opt.grid_mult = n_lanes > 1 ? 1 : 8;
-            // Scenes whose tree lives in HBM / L2 (quad form) wait for node fetches and gain from more waves of a kernel in flight once a
-            // segment still holds ~10 k paths: classroom (66 M paths per pass) 801 -> 797 / 784 / 795 ms at 4 096 / 6 144 / 8 192 segments,
-            // colonnade (15 M per pass) 107.3 -> 110.2 / 112.9 / 115.9: it stays at 2 048.  (The LDS-resident Cornell, bound by what the
-            // SIMDs issue, loses 1 % at 4 096.)
             if (n_lanes > 1 && ps->sc.n_nodes4 != 0) {
-                const uint64_t per_pass = job_paths / n_lanes, per_unit = (uint64_t)ps->n_cu * 8u * 10240u;
-                const uint64_t k = (per_pass + per_unit / 2) / per_unit;
+                const uint64_t per_unit = (uint64_t)ps->n_cu * 8u * 10240u;
+                const uint64_t k = (max_paths + per_unit / 2) / per_unit;
                 opt.grid_mult = (int)(k < 1 ? 1 : (k > 4 ? 4 : k));
             }
             if (opt.grid_pct == 0) opt.grid_pct = 100;
         }
         if (opt.grid_pct == 0) opt.grid_pct = n_lanes > 1 ? 50 : 100; // (several lanes with many segments each: a launch takes half of its resident capacity)
-        return n_lanes;
     }
     void select(uint32_t l) {
         if (l == cur) return;
@@ -1423,6 +1462,7 @@ struct HipBackend {
 
     int begin(const DScene &sc_, const DSampler &S_, const DCamera &C_, uint32_t capacity, uint32_t count_rows, uint32_t bvh_depth, uint32_t flags_, int feat_, int feat_trace_, std::string &err) {
         sc = sc_; S = S_; C = C_; cap = capacity; rows = count_rows; depth = bvh_depth; flags = flags_; feat = feat_; feat_trace = feat_trace_;
+        plan_segments(capacity);
         // phase voting: quad-node scenes gain in both traversal kernels; on the LDS pair form a step is cheap enough that the vote's
         // own instructions eat the gain in the connect kernel (+20 %), the extension kernel keeps 4 % (A/B on MI355X)
         vote = opt.vote >= 0 ? opt.vote != 0 : true;
@@ -1438,6 +1478,10 @@ struct HipBackend {
         if (opt.persist && opt.whole_rounds) grid_max = (int)(feat_trace == FEAT_FULL ? whole_rounds<FEAT_FULL>((uint32_t)grid_max) : (feat_trace == FEAT_IMG_ENV ? whole_rounds<FEAT_IMG_ENV>((uint32_t)grid_max) : whole_rounds<FEAT_SIMPLE>((uint32_t)grid_max)));
         const size_t n16 = (size_t)cap * 16, n4 = ((size_t)cap + ((size_t)grid_max + 1) * 64) * 4; // queues: G segments of whole 64-entry chunks
         if ((rc = ps->stats.ensure(CNT_NUM * 8)) != PTRS_OK || (rc = ps->table.ensure(1024)) != PTRS_OK) { err = g_err; return rc; }
+        if (ps->spill_lane_elems) { // the traversal stacks' global columns: one set per pipeline lane of THIS render (concurrent lanes must not share columns)
+            if ((rc = ps->stack_spill.ensure(ps->spill_lane_elems * n_lanes * sizeof(unsigned long long))) != PTRS_OK) { err = g_err + " (traversal stack spill columns)"; return rc; }
+            ps->spill.p = (unsigned long long *)ps->stack_spill.p;
+        }
         for (uint32_t l = 0; l < n_lanes && n_lanes > 1; ++l) {
             if (l > 0 && !ps->lane_stream[l] && hipStreamCreateWithFlags(&ps->lane_stream[l], hipStreamNonBlocking) != hipSuccess) { err = "cannot create a pipeline stream"; return PTRS_ERR_DEVICE; }
             if (!ps->lane_ev[l] && hipEventCreateWithFlags(&ps->lane_ev[l], hipEventDisableTiming) != hipSuccess) { err = "cannot create pipeline events"; return PTRS_ERR_DEVICE; }
@@ -1688,7 +1732,7 @@ struct HipBackend {
         size_t bytes = 0;
         for (auto &l : ps->ws) for (auto &b : l) bytes += b.bytes;
         for (auto &b : ps->counts) bytes += b.bytes;
-        st.device_bytes = bytes + ps->film_tmp.bytes + ps->samples_tmp.bytes;
+        st.device_bytes = bytes + ps->film_tmp.bytes + ps->samples_tmp.bytes + ps->stack_spill.bytes + ps->row_cost.bytes;
     }
 };
 
@@ -1798,7 +1842,7 @@ static int scene_create_impl(const PtrsSceneDesc *desc, int32_t device, PtrsScen
     if (H.stack_bound > ps->stack_lds) {
         const size_t threads = (size_t)ps->n_cu * 8 * BLOCK; // no launch holds more than 8 workgroups per CU
         ps->spill_lane_elems = threads * (size_t)(H.stack_bound - ps->stack_lds);
-        if ((rc = ps->stack_spill.ensure(ps->spill_lane_elems * MAX_LANES * sizeof(unsigned long long))) != PTRS_OK) { delete ps; return rc; } // concurrent lanes must not share columns
+        if ((rc = ps->stack_spill.ensure(ps->spill_lane_elems * sizeof(unsigned long long))) != PTRS_OK) { delete ps; return rc; } // one lane's worth (ptrs_trace_rays / ptrs_trace_bench); a render grows it to its lanes (HipBackend::begin)
         ps->spill.p = (unsigned long long *)ps->stack_spill.p; ps->spill.stride = (uint32_t)threads;
     }
     *out = ps;
@@ -2121,6 +2165,7 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
         be.geom4 = be.sc.n_nodes4 ? 0xffffffffu : LN_V4 * be.sc.n_nodes2 + 9u * be.sc.n_prims;
         const uint32_t chunks = (n + 63u) / 64u, gmax = (uint32_t)scene->n_cu * 8u * (uint32_t)(be.opt.grid_mult ? be.opt.grid_mult : 8); // (one launch at a time: the single-lane segmentation)
         const uint32_t G = chunks < gmax ? chunks : gmax, seg_cap = ((chunks + G - 1) / G) * 64u;
+        if ((uint64_t)G * seg_cap * 16ull >= (1ull << 32)) { g_err = "ptrs_trace_bench: too many rays for one launch (queue positions are 32-bit byte offsets of 16-byte records: fewer than 2^28)"; return PTRS_ERR_INVALID; }
         be.G = G; be.seg_cap = seg_cap;
         // the rays in queue order, as a frame's shade stage leaves them: ray i = 64 c + k sits at position (c mod G) seg_cap + (c / G) 64 + k
         const size_t nq = (size_t)G * seg_cap;
@@ -2148,8 +2193,8 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
         StackSpill sp = scene->spill;
         const HipBackend::TravFn fn = be.feat_trace == FEAT_FULL ? be.pick_extend<FEAT_FULL>(be.vote, sp.p != nullptr) : (be.feat_trace == FEAT_IMG_ENV ? be.pick_extend<FEAT_IMG_ENV>(be.vote, sp.p != nullptr) : be.pick_extend<FEAT_SIMPLE>(be.vote, sp.p != nullptr));
         const uint32_t grid = be.persistent_grid(fn, HipBackend::T_EXTEND);
-        std::vector<hipEvent_t> ev(2 * (size_t)repeats);
-        for (auto &x : ev) if (e == hipSuccess) e = hipEventCreate(&x);
+        std::vector<hipEvent_t> ev(2 * (size_t)repeats, nullptr);
+        for (auto &x : ev) if (e == hipSuccess) e = hipEventCreate(&x); // (destroyed below on every path: nothing between here and there returns)
         for (uint32_t k = 0; k <= repeats && e == hipSuccess; ++k) { // launch 0 counts nodes and triangles (untimed), 1 .. repeats are timed
             R.counters_on = k == 0 ? 1u : 0u;
             if (k) (void)hipEventRecord(ev[2 * (k - 1)], nullptr);
