@@ -139,6 +139,8 @@ def kernel_class(name):
         return "traversal"
     if name.startswith("k_shade"):
         return "shade"
+    if name.startswith("k_tail"):
+        return "tail"  # the fused late rounds: traversal and shading of thin segments in one kernel
     if name.startswith("k_film"):
         return "film"
     return "aux"
@@ -442,6 +444,8 @@ def main():
     ap.add_argument("--even-bands", action="store_true", help="N > 1: bands of equal height instead of equal cost")
     ap.add_argument("--rehearse", action="store_true", help="the multi-rank plumbing only (launch, process group, band plan, film gather), no render: runs without a GPU over gloo")
     ap.add_argument("--profile", action="store_true", help="for rocprofv3 runs: render exactly --steps frames on ONE pipeline lane (no counter / warm-up frames, no JSON)")
+    ap.add_argument("--tail-at", type=int, default=-2, help="--profile: the round at which the profiled single-lane frames hand over to the fused tail (-1: no tail); tools/prof.sh passes what --print-tail-at printed, so that the profiled frame is launched like the bench's own single-lane frame")
+    ap.add_argument("--print-tail-at", action="store_true", help="prints the hand-over round of this workload's single-lane frame (after the frame that teaches the library the scene's survival profile) and exits")
     ap.add_argument("--rays", default="", help="trace workloads: an .npz of ray sets; written (and nothing else done) when it does not exist, read instead of rendering when it does")
     ap.add_argument("--node-order", type=int, default=-1, help="trace workloads: quad-node order behind the LDS-cached top (0 depth-first, 1 treelets)")
     ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS) + sorted(TRACE_WORKLOADS),
@@ -543,8 +547,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.profile:
+    if args.print_tail_at:
+        step(0)  # (the scene's survival profile, as the bench's own first frame leaves it)
         with pkg.options(lanes=1):
+            st = step(0)
+            sync()
+        print(int(st.tail_round) if st.tail_launches else -1)
+        return
+    if args.profile:
+        pin = {} if args.tail_at == -2 else ({"tail": 0} if args.tail_at < 0 else {"tail_at": args.tail_at})
+        with pkg.options(lanes=1, **pin):
             for _ in range(args.steps):
                 st = step(0)
             sync()
@@ -593,6 +605,7 @@ def main():
         classes = {
             "traversal": class_roofline("traversal", xst.ms_extend + xst.ms_connect, xst.extend_launches + xst.connect_launches, pmc, algorithmic_bytes=xst.rays * b_ray),
             "shade": class_roofline("shade", xst.ms_shade_kernels, xst.shade_launches, pmc),
+            "tail": class_roofline("tail", xst.ms_tail, xst.tail_launches, pmc),
         }
         dom = max(classes, key=lambda k: classes[k]["ms_per_frame_single_lane"])
         d = classes[dom]

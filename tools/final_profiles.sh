@@ -18,7 +18,7 @@ done
 timeout -k 10 600 python bench.py > $OUT/r04_bench_cornell.json || exit 1
 timeout -k 10 600 python bench.py --workload colonnade --no-collective-smoke > $OUT/r04_bench_colonnade.json || exit 1
 timeout -k 10 600 python bench.py --workload classroom --no-collective-smoke > $OUT/r04_bench_classroom.json || exit 1
-tools/trace_profiles.sh || exit 1
+if [ -z "$SKIP_TRACE" ]; then tools/trace_profiles.sh || exit 1; fi
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/final/r04_bench_*.json")):

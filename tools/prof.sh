@@ -10,6 +10,9 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 CMD="python3 bench.py --workload $W --steps $FR --profile"
+case $W in trace-*) ;; *) # the profiled single-lane frame hands over to the fused tail where the bench's own single-lane frame does (an unprofiled run finds the round)
+  K=$(python3 bench.py --workload $W --print-tail-at 2> "$OUT/tail_at.log" | tail -n 1); echo "tail_at $K"; CMD="$CMD --tail-at $K";;
+esac
 case $W in trace-*) # the ray sets are made by an unprofiled run, so that the profiled processes launch the traced kernel only
   rm -f /tmp/rays_$W.npz; python3 bench.py --workload $W --rays /tmp/rays_$W.npz > "$OUT/rays.log" 2>&1
   CMD="$CMD --rays /tmp/rays_$W.npz";;
