@@ -55,6 +55,7 @@ struct Options {
     int shade_lds = 1;        // shade kernels read light records, small scenes' triangle records and the round's Sobol' tables from LDS (0: everything from global memory)
     int env_presample = 1;    // scenes lit by an environment map: the light's samples of a round's vertices are evaluated by k_env_presample ahead of the shade kernels (0: inside them)
     int peer_copy = 1;        // ptrs_render_multi: bands travel device to device (hipMemcpyPeerAsync over xGMI); 0: staged through the host film, the path taken when two devices cannot reach each other (test hook)
+    int deal = 0;             // how k_generate deals a pass's 64-path chunks to the queue segments: 0 round-robin (every segment a sample of the whole image: even load), 1 by image region (a segment = a patch of pixels with all its samples; segment ranges follow the ticket counters and those the XCDs: an XCD's L2 serves one region's rays -- measured 4-7 % SLOWER on all three workloads: the regions' paths die at different rates and the segments' loads with them)
     int tail = 1;             // thin late rounds of a pass run in ONE launch (k_tail: every wave takes its segment through all remaining rounds) where the scene has an instantiation; 0: every round is its three launches
     int tail_at = -1;         // the round at which a pass hands over to k_tail: -1 = the first round in which the paths expected alive (this scene's survival profile, learned from its last finished pass) are at most tail_paths per segment; k >= 0: round k
     int tail_paths = 0;       // (tail_at = -1) paths per segment at or below which the tail takes over; 0 = the measured default (TAIL_PATHS_DEFAULT)
@@ -66,7 +67,7 @@ Options options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
 struct OptionDesc { const char *name; int Options::*field; int lo, hi; };
 const OptionDesc k_options[] = {
     {"lanes", &Options::lanes, 0, 8}, {"refill", &Options::refill, -1, 64}, {"refill_connect", &Options::refill_connect, -1, 64}, {"stack_lds", &Options::stack_lds, 8, 16},
-    {"grid_mult", &Options::grid_mult, 0, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1}, {"env_presample", &Options::env_presample, 0, 1}, {"tail", &Options::tail, 0, 1}, {"tail_at", &Options::tail_at, -1, 64}, {"tail_paths", &Options::tail_paths, 0, 1 << 20},
+    {"grid_mult", &Options::grid_mult, 0, 64}, {"persist", &Options::persist, 0, 1}, {"whole_rounds", &Options::whole_rounds, 0, 1}, {"grid_pct", &Options::grid_pct, 0, 100}, {"node_form", &Options::node_form, 0, 2}, {"node_order", &Options::node_order, 0, 1}, {"vote", &Options::vote, -1, 2}, {"shade_lds", &Options::shade_lds, 0, 1}, {"fused_epilogue", &Options::fused_epilogue, 0, 1}, {"fused_resolve", &Options::fused_resolve, 0, 1}, {"workspace_pct", &Options::workspace_pct, 1, 90}, {"peer_copy", &Options::peer_copy, 0, 1}, {"env_presample", &Options::env_presample, 0, 1}, {"deal", &Options::deal, 0, 1}, {"tail", &Options::tail, 0, 1}, {"tail_at", &Options::tail_at, -1, 64}, {"tail_paths", &Options::tail_paths, 0, 1 << 20},
 };
 
 #define HIPCHK(expr)                                                                                             \
@@ -199,22 +200,56 @@ struct LdsStack { // records are packed into one 64-bit word (ref | entry distan
 };
 
 // ---- kernels ----------------------------------------------------------------------------------------
-// Wave s generates the paths of segment s: chunks of 64 consecutive path slots are dealt round-robin to the G segments
-// (coalesced state access per wave -- 1 KB per state array and chunk -- and an even load across segments).
-__global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCamera C, DPaths P, DQueues Q, uint32_t seg_cap, uint32_t G) {
+// Wave s generates the paths of segment s.  The pass's path slots -- sample-major: slot = sample x pixels + pixel -- are cut into chunks
+// of 64 consecutive slots (coalesced state access per wave: 1 KB per state array and chunk), and the chunks are dealt to the G segments
+//   deal = 0: round-robin (chunk c to segment c mod G): every segment holds paths of the whole image;
+//   deal = 1: BY IMAGE REGION: the chunks form a matrix (rows: samples, columns: the ~pixels / 64 chunks of one sample's pixels) that
+//             is walked column by column, and segment s takes the s-th run of ceil(chunks / G) cells: a segment holds a few columns --
+//             a patch of neighbouring pixels -- with ALL their samples, and neighbouring segments neighbouring patches.  Segments keep
+//             their identity through every stage of every round (the wave that consumes segment s appends only to segment s), the
+//             ticket counters hand out contiguous segment ranges, and a workgroup's home counter follows blockIdx mod 16, i.e. its XCD
+//             (workgroups are placed round-robin over the 8 XCDs): an XCD's private L2 then serves the rays of an eighth of the image
+//             -- primary and shadow rays of one region walk the same part of the tree -- instead of a sample of all of it.  When a
+//             range runs dry its waves move on to the next counter's (the neighbouring region).  Placement is a matter of speed only.
+// Either way a segment's entries are compact (positions e0 .. e0 + n) and hold at most seg_cap = ceil(chunks / G) x 64 paths.
+__global__ __launch_bounds__(BLOCK) void k_generate(DParams R, DSampler S, DCamera C, DPaths P, DQueues Q, uint32_t seg_cap, uint32_t G, uint32_t deal) {
     const uint32_t lane = threadIdx.x & 63u, s = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (s >= G) return;
     const uint32_t chunks = (R.n_paths + 63u) / 64u;
     const uint32_t e0 = s * seg_cap; // the segment's first position in the queue-ordered arrays
     uint32_t n = 0;
-    for (uint32_t c = s; c < chunks; c += G) {
-        const uint32_t pid = c * 64u + lane;
-        if (pid < R.n_paths) {
-            const uint32_t e = e0 + (c / G) * 64u + lane;
-            generate_item(R, S, C, P, pid, e);
-            pslot(Q.ext[0], e) = pid;
+    if (!deal) {
+        for (uint32_t c = s; c < chunks; c += G) {
+            const uint32_t pid = c * 64u + lane;
+            if (pid < R.n_paths) {
+                const uint32_t e = e0 + (c / G) * 64u + lane;
+                generate_item(R, S, C, P, pid, e);
+                pslot(Q.ext[0], e) = pid;
+            }
+            n += (c * 64u + 64u <= R.n_paths) ? 64u : (R.n_paths - c * 64u);
         }
-        n += (c * 64u + 64u <= R.n_paths) ? 64u : (R.n_paths - c * 64u);
+    } else {
+        const uint32_t npix = R.pixel_mode ? 1u : (uint32_t)(R.row1 - R.row0) * (uint32_t)R.NX;
+        uint32_t cpp = (npix + 63u) / 64u; // columns: the chunks of one sample's pixels (when pixels % 64 != 0 a row drifts by a fraction of a chunk per sample: nothing to a region)
+        if (cpp > chunks) cpp = chunks;
+        if (cpp < 1u) cpp = 1u;
+        const uint32_t nsr = (chunks + cpp - 1u) / cpp;          // rows
+        const uint32_t r_last = chunks - (nsr - 1u) * cpp;       // the columns that have a cell in the last row
+        const uint32_t full = r_last * nsr;                      // cells of those columns in column-major order; the columns behind them have nsr - 1 cells
+        const uint32_t cps = seg_cap / 64u;
+        const uint32_t c1 = (s + 1u) * cps < chunks ? (s + 1u) * cps : chunks;
+        for (uint32_t cc = s * cps; cc < c1; ++cc) {
+            uint32_t pc, k;
+            if (cc < full) { pc = cc / nsr; k = cc - pc * nsr; }
+            else { const uint32_t d = cc - full, q = d / (nsr - 1u); pc = r_last + q; k = d - q * (nsr - 1u); } // (full < chunks only when nsr >= 2)
+            const uint32_t c = k * cpp + pc, pid = c * 64u + lane;
+            if (pid < R.n_paths) {
+                const uint32_t e = e0 + n + lane; // (only the pass's last chunk is partial, and its paths are its first lanes: positions stay compact)
+                generate_item(R, S, C, P, pid, e);
+                pslot(Q.ext[0], e) = pid;
+            }
+            n += (c * 64u + 64u <= R.n_paths) ? 64u : (R.n_paths - c * 64u);
+        }
     }
     if (lane == 0) *seg_count(Q, 0, Q_EXT, G, s) = n;
 }
@@ -1534,7 +1569,8 @@ struct HipBackend {
         (void)hipMemsetAsync(Q.counts, 0, (size_t)rows * Q_STRIDE * G * 4, stream);
         (void)hipMemsetAsync(Q.tickets, 0, ((size_t)rows * Q_STRIDE * TK_LAUNCH_WORDS + rows) * 4, stream); // (+ the alive flags behind them)
     }
-    void generate() { t0(T_AUX); hipLaunchKernelGGL(k_generate, dim3((G + WAVES - 1) / WAVES), dim3(BLOCK), 0, stream, R, S, C, P, Q, seg_cap, G); t1(); }
+    void generate() { t0(T_AUX); hipLaunchKernelGGL(k_generate, dim3((G + WAVES - 1) / WAVES), dim3(BLOCK), 0, stream, R, S, C, P, Q, seg_cap, G, (uint32_t)deal_by_region()); t1(); }
+    int deal_by_region() const { return opt.deal; } // (option `deal`: measured slower, off)
 
     // the instantiation of a traversal kernel for this scene: LDS stack depth, spill columns, geometry source, phase voting
     typedef void (*TravFn)(DParams, DScene, StackSpill, DPaths, DQueues, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *);
@@ -2167,14 +2203,19 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
         const uint32_t G = chunks < gmax ? chunks : gmax, seg_cap = ((chunks + G - 1) / G) * 64u;
         if ((uint64_t)G * seg_cap * 16ull >= (1ull << 32)) { g_err = "ptrs_trace_bench: too many rays for one launch (queue positions are 32-bit byte offsets of 16-byte records: fewer than 2^28)"; return PTRS_ERR_INVALID; }
         be.G = G; be.seg_cap = seg_cap;
-        // the rays in queue order, as a frame's shade stage leaves them: ray i = 64 c + k sits at position (c mod G) seg_cap + (c / G) 64 + k
+        // the rays in queue order, as a frame's shade stage leaves them: ray i = 64 c + k sits at position (c mod G) seg_cap + (c / G) 64 + k, or
+        // -- option `deal` -- in runs of whole segments ((c / cps) seg_cap + (c mod cps) 64 + k): a dump of a frame
+        // dealt by image region comes segment by segment, and so keeps its regions
+        const uint32_t cps = seg_cap / 64u; const bool by_region = be.deal_by_region() != 0;
+        auto seg_of = [&](uint32_t c) { return by_region ? c / cps : c % G; };
+        auto pos_of = [&](uint32_t c) { return (size_t)seg_of(c) * seg_cap + (size_t)(by_region ? c % cps : c / G) * 64u; };
         const size_t nq = (size_t)G * seg_cap;
         std::vector<v4> ro(nq), rd(nq);
         std::vector<uint32_t> q(nq, 0u), cnt((size_t)Q_STRIDE * G, 0u);
         for (uint32_t c = 0; c < chunks; ++c) {
-            const uint32_t s = c % G, m = c * 64u + 64u <= n ? 64u : n - c * 64u;
+            const uint32_t s = seg_of(c), m = c * 64u + 64u <= n ? 64u : n - c * 64u;
             for (uint32_t k = 0; k < m; ++k) {
-                const uint32_t i = c * 64u + k; const size_t e = (size_t)s * seg_cap + (c / G) * 64u + k;
+                const uint32_t i = c * 64u + k; const size_t e = pos_of(c) + k;
                 q[e] = i;
                 ro[e].x = rays[7 * i]; ro[e].y = rays[7 * i + 1]; ro[e].z = rays[7 * i + 2]; ro[e].w = rays[7 * i + 6]; rd[e].x = rays[7 * i + 3]; rd[e].y = rays[7 * i + 4]; rd[e].z = rays[7 * i + 5]; rd[e].w = 0.0f;
             }
@@ -2215,9 +2256,9 @@ int ptrs_trace_bench(PtrsScene *scene, uint32_t n, const float *rays, uint32_t r
             std::vector<u4> hh(nq);
             e = hipMemcpy(hh.data(), bh.p, nq * 16, hipMemcpyDeviceToHost);
             for (uint32_t c = 0; c < chunks; ++c) {
-                const uint32_t s = c % G, m = c * 64u + 64u <= n ? 64u : n - c * 64u;
+                const uint32_t m = c * 64u + 64u <= n ? 64u : n - c * 64u;
                 for (uint32_t k = 0; k < m; ++k) {
-                    const uint32_t i = c * 64u + k; const u4 h = hh[(size_t)s * seg_cap + (c / G) * 64u + k];
+                    const uint32_t i = c * 64u + k; const u4 h = hh[pos_of(c) + k];
                     hits_out[i].prim = hit_prim(h.x); hits_out[i].b0 = u2f(h.y); hits_out[i].b1 = u2f(h.z); hits_out[i].b2 = u2f(h.w); hits_out[i].t = 0.0f;
                 }
             }

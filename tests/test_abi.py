@@ -61,7 +61,7 @@ def test_options_api():
     import importlib
     ptrs = importlib.import_module("pathtracer-rs_amd")
     L = ptrs.load_library()
-    defaults = {"lanes": 0, "grid_pct": 0, "refill": -1, "refill_connect": -1, "vote": -1, "shade_lds": 1, "fused_epilogue": 1, "fused_resolve": 1, "stack_lds": 8, "grid_mult": 0, "persist": 1, "whole_rounds": 0, "node_order": 0, "peer_copy": 1, "env_presample": 1, "node_form": 0, "workspace_pct": 40, "tail": 1, "tail_at": -1, "tail_paths": 0}
+    defaults = {"lanes": 0, "grid_pct": 0, "refill": -1, "refill_connect": -1, "vote": -1, "shade_lds": 1, "fused_epilogue": 1, "fused_resolve": 1, "stack_lds": 8, "grid_mult": 0, "persist": 1, "whole_rounds": 0, "node_order": 0, "peer_copy": 1, "env_presample": 1, "node_form": 0, "workspace_pct": 40, "tail": 1, "tail_at": -1, "tail_paths": 0, "deal": 0}
     for k, v in defaults.items():
         assert ptrs.get_option(k) == v, k
     with ptrs.options(lanes=1, vote=0):

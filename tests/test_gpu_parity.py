@@ -142,6 +142,11 @@ def test_shipped_four_lane_schedule_matches_oracle(ptrs, orc, scenes):
     _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15, lanes=4)
     cam, scene = scenes.material_zoo((120, 80))
     _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15, lanes=4)
+    # how k_generate deals the chunks of a pass to the segments (round-robin, the default / by image region)
+    cam, scene = ptrs.import_scene(CORNELL, (61, 47))  # (pixels % 64 != 0: the chunk matrix's rows drift)
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 8, 15, lanes=4, deal=1)
+    cam, scene = scenes.colonnade((160, 90))
+    _gpu_vs_oracle(ptrs, orc, cam, scene, 4, 15, lanes=4, deal=1)
 
 
 def test_fused_tail_matches_oracle(ptrs, orc, scenes):
@@ -282,6 +287,7 @@ def test_launch_policy_options_do_not_change_the_film(ptrs):
     cases = [(lambda: ptrs.import_scene(CORNELL, (96, 80)), 16, 8, 30000), (lambda: scenes_mod.material_zoo((72, 48)), 8, 15, 20000)]
     combos = [{}, {"lanes": 1}, {"lanes": 4, "grid_pct": 10}, {"grid_mult": 1, "persist": 0}, {"grid_mult": 64, "whole_rounds": 1}, {"lanes": 3, "grid_pct": 100, "grid_mult": 3},
               {"lanes": 2, "fused_epilogue": 0, "grid_mult": 2}, {"lanes": 4, "node_form": 2}, {"lanes": 4, "node_form": 2, "grid_mult": 3},  # (node_form 2: quad nodes with per-axis planes out of global memory)
+              {"deal": 0}, {"deal": 1}, {"deal": 1, "lanes": 4, "tail_at": 2}, {"deal": 1, "grid_mult": 3, "lanes": 2}, {"deal": 1, "node_form": 2, "lanes": 4},  # chunks dealt to segments round-robin / by image region
               {"tail": 0}, {"tail_at": 0}, {"tail_at": 1, "lanes": 4}, {"tail_at": 3, "grid_mult": 2}, {"tail_at": 5, "lanes": 1}, {"tail_at": 2, "node_form": 2, "lanes": 4}]  # the fused tail from round k on (Cornell has an instantiation, the zoo -- every material kind -- has none: the knob is inert there)
     for scene_fn, spp, depth, ppp in cases:
         ref, st0 = film(scene_fn, combos[0], spp, depth, ppp)
