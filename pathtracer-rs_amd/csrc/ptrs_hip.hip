@@ -189,6 +189,8 @@ struct LdsStack { // records are packed into one 64-bit word (ref | entry distan
         if (!OVF || n < D) col[n * BLOCK] = e; else ovf[(size_t)(n - D) * ovf_stride] = e;
         ++n;
     }
+    static constexpr bool select_push = !OVF; // (a stack without overflow can push in select form: the store goes out for every lane, the count moves for those that push)
+    __device__ inline void push_if(bool yes, uint32_t v, float t) { col[n * BLOCK] = (unsigned long long)v | ((unsigned long long)f2u(t) << 32); n += yes ? 1 : 0; }
     __device__ inline void pop(uint32_t &v, float &t) {
         --n;
         unsigned long long e = col[(OVF && n >= D ? D - 1 : n) * BLOCK]; // always an LDS read (no generic-address select); the spill is the rare path
@@ -380,6 +382,13 @@ __device__ inline void lf_node_visit(uint32_t &cur, f3 o, f3 inv, uint32_t ox, u
     // (h0 & h1, h0 | h1 on the lane masks themselves -- s_and_b64 / s_or_b64 -- instead of the 0 / 1 integers in vector registers the
     // compiler makes of two booleans that feed several branches)
     const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+    if (Stack::select_push) { // no divergent region around the push and the one-child case: selects, one unconditional LDS store, and the pop as the only branch
+        const bool both = __builtin_amdgcn_inverse_ballot_w64(m0 & m1);
+        stack.push_if(both, second_first ? ref0 : ref1, second_first ? t0 : t1);
+        cur = both ? (second_first ? ref1 : ref0) : (h0 ? ref0 : ref1);
+        if (!__builtin_amdgcn_inverse_ballot_w64(m0 | m1)) cur = pop_next_ref<false>(stack, t_max);
+        return;
+    }
     if (__builtin_amdgcn_inverse_ballot_w64(m0 & m1)) { stack.push(second_first ? ref0 : ref1, second_first ? t0 : t1); cur = second_first ? ref1 : ref0; }
     else if (__builtin_amdgcn_inverse_ballot_w64(m0 | m1)) cur = h0 ? ref0 : ref1;
     else cur = pop_next_ref<false>(stack, t_max);
@@ -492,7 +501,12 @@ __device__ inline void resolve_wave(const DScene &sc, const DPaths &P, const DQu
 #ifndef PTRS_LDS_WAVES
 #define PTRS_LDS_WAVES 6
 #endif
-template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = GEOM == 640 ? PTRS_LDS_WAVES : ((GEOM == 0 && DEPTH == 8) ? PTRS_QUAD_WAVES : 0) }; };
+template <int FEAT, int DEPTH, int GEOM> struct TravWaves { enum { N = (GEOM == 640 || GEOM == 544) ? PTRS_LDS_WAVES : ((GEOM == 0 && DEPTH == 8) ? PTRS_QUAD_WAVES : 0) }; };
+// (GEOM = 544 with a 9-entry column: a small scene whose pair tree is one level deeper than the 8-entry column -- Cornell: 527 vectors of LDS form, depth 9 --
+// gets the column it needs and a staging area cut to fit: 18 432 + 8 704 B, six workgroups per CU like the 8 / 640 form, and kernels WITHOUT overflow code, whose
+// node visit pushes in select form (lf_node_visit).  Alone the 9 / 544 form measured within noise of 8 / 640 + overflow; with the select-form push the
+// four-lane Cornell frame went 142.96 -> 139.22 ms (ABAB x 3), the single-lane kernels unchanged: fewer scalar instructions to share the SIMDs' scalar port among
+// the lanes' kernels.)
 template <int DEPTH, int GEOM> struct TravLds { enum { TOP = GEOM == 0 && DEPTH == 8, V4 = GEOM > 0 ? GEOM : (TOP ? TOP_LDS_STRIDE * QUAD_TOP_NODES : 1) }; }; // quad form with the small stack column: the tree's top lives in LDS
 
 // Diagnostic builds only (-DPTRS_STAMPS_EXT, tools/ablate.sh + tools/stamps_ext.py): wave clocks of the phases of the extension stage, summed
@@ -978,10 +992,10 @@ __global__ __launch_bounds__(BLOCK, (ShadeWaves<MAT, FEAT>::N)) void k_shade(DPa
 // the waves of a workgroup are in different rounds: draws read the global tables (sob_n = 0).
 // Instantiated for scenes of ONE material bucket whose traversal kernels are the lean ones (Cornell: Matte; colonnade: Disney +
 // image textures); two workgroups per CU (the Matte shade stage's registers, the LDS of both stages).
-template <int MAT, int FEAT, int GEOM, bool OVF>
+template <int MAT, int FEAT, int GEOM, bool OVF, int DEPTH = 8>
 __global__ __launch_bounds__(BLOCK, 2) void k_tail(DParams R, DSampler S, DCamera C, DScene sc, StackSpill spill, DPaths P, DQueues Q, uint32_t it0, uint32_t it_end, uint32_t seg_cap, uint32_t thresh_e, uint32_t thresh_c,
                                                    uint32_t kinds_mask, ShadeLdsCfg cfg, uint32_t Gn, uint32_t *ticket) {
-    constexpr int DEPTH = 8, FEAT_T = FEAT_SIMPLE;
+    constexpr int FEAT_T = FEAT_SIMPLE;
     constexpr bool VOTE_C = GEOM == 0; // (the launch policy's defaults: phase voting in the connection stage for quad-form scenes only)
     __shared__ unsigned long long lds_stack[DEPTH * BLOCK];
     __shared__ v4 lds_geom[TravLds<DEPTH, GEOM>::V4];
@@ -1575,7 +1589,7 @@ struct HipBackend {
     // the instantiation of a traversal kernel for this scene: LDS stack depth, spill columns, geometry source, phase voting
     typedef void (*TravFn)(DParams, DScene, StackSpill, DPaths, DQueues, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *);
 #define PTRS_PICK(K, D, O, GE) (v ? (TravFn)K<FEAT, D, O, GE, true> : (TravFn)K<FEAT, D, O, GE, false>)
-#define PTRS_PICK_ALL(K) (ps->stack_lds == 8 ? (geom4 <= 640 ? (ovf ? PTRS_PICK(K, 8, true, 640) : PTRS_PICK(K, 8, false, 640)) : geom4 <= 1536 ? (ovf ? PTRS_PICK(K, 8, true, 1536) : PTRS_PICK(K, 8, false, 1536)) : (ovf ? PTRS_PICK(K, 8, true, 0) : PTRS_PICK(K, 8, false, 0))) \
+#define PTRS_PICK_ALL(K) (ps->stack_lds == 9 ? PTRS_PICK(K, 9, false, 544) : ps->stack_lds == 8 ? (geom4 <= 640 ? (ovf ? PTRS_PICK(K, 8, true, 640) : PTRS_PICK(K, 8, false, 640)) : geom4 <= 1536 ? (ovf ? PTRS_PICK(K, 8, true, 1536) : PTRS_PICK(K, 8, false, 1536)) : (ovf ? PTRS_PICK(K, 8, true, 0) : PTRS_PICK(K, 8, false, 0))) \
                                               : (ovf ? PTRS_PICK(K, 16, true, 0) : PTRS_PICK(K, 16, false, 0)))
     template <int FEAT> TravFn pick_extend(bool v, bool ovf) { return PTRS_PICK_ALL(k_extend_rf); }
     template <int FEAT> TravFn pick_connect(bool v, bool ovf) { return PTRS_PICK_ALL(k_connect_rf); }
@@ -1661,10 +1675,11 @@ struct HipBackend {
     typedef void (*TailFn)(DParams, DSampler, DCamera, DScene, StackSpill, DPaths, DQueues, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, ShadeLdsCfg, uint32_t, uint32_t *);
     enum : uint32_t { TAIL_PATHS_DEFAULT = 192 }; // measured (tools/tail_sweep.sh): flat between 64 and 384 paths per segment for every job size; below, thin rounds stay three launches each, above, thick rounds run at the tail's two waves per SIMD
     TailFn tail_fn() { // the instantiation for this scene, or null: one material bucket, the lean traversal kernels, the 8-entry stack column, the fused epilogue / resolve
-        if (!opt.tail || !opt.fused_epilogue || !opt.fused_resolve || !opt.shade_lds || !opt.persist || ps->stack_lds != 8 || feat_trace != FEAT_SIMPLE || S.kind != PTRS_SAMPLER_SOBOL) return nullptr;
+        if (!opt.tail || !opt.fused_epilogue || !opt.fused_resolve || !opt.shade_lds || !opt.persist || (ps->stack_lds != 8 && ps->stack_lds != 9) || feat_trace != FEAT_SIMPLE || S.kind != PTRS_SAMPLER_SOBOL) return nullptr;
         int kind = -1;
         for (int k = 0; k < 7; ++k) if (ps->H.kinds_present[k]) { if (kind >= 0) return nullptr; kind = k; }
         const bool ovf = ps->spill.p != nullptr;
+        if (ps->stack_lds == 9) return (kind == PTRS_MAT_MATTE && feat == FEAT_SIMPLE) ? (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 544, false, 9> : nullptr;
         if (kind == PTRS_MAT_MATTE && feat == FEAT_SIMPLE) {
             if (geom4 <= 640) return ovf ? (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 640, true> : (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 640, false>;
             if (geom4 <= 1536) return ovf ? (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 1536, true> : (TailFn)k_tail<PTRS_MAT_MATTE, FEAT_SIMPLE, 1536, false>;
@@ -1875,6 +1890,7 @@ static int scene_create_impl(const PtrsSceneDesc *desc, int32_t device, PtrsScen
     // against a 16-entry column without the cache: +2 % on colonnade, +1 % on classroom).  the option stack_lds = 16 selects that
     // older layout for quad-form scenes.
     ps->stack_lds = (H.use_quad && opt.stack_lds == 16) ? 16u : 8u;
+    if (!H.use_quad && opt.stack_lds != 16 && H.stack_bound == 9u && LN_V4 * (uint32_t)H.nodes2.size() + 9u * (uint32_t)H.tris.size() <= 544u) ps->stack_lds = 9u; // the 9 / 544 LDS form (TravWaves): no overflow code
     if (H.stack_bound > ps->stack_lds) {
         const size_t threads = (size_t)ps->n_cu * 8 * BLOCK; // no launch holds more than 8 workgroups per CU
         ps->spill_lane_elems = threads * (size_t)(H.stack_bound - ps->stack_lds);
