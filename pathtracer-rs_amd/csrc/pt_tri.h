@@ -67,6 +67,44 @@ PT_HD bool tri_test_perm(f3 p0t, f3 p1t, f3 p2t, float sx, float sy, float sz, f
     h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
     return true;
 }
+// tri_test_perm in select form: the same arithmetic in the same order, every rejection a term of one predicate instead of an early
+// return.  On gfx950 an early return inside a wave's step is a divergent region (exec-mask save / restore, a branch, the waits around
+// them: scalar instructions, of which a SIMD issues one per ~4 cycles for all its waves); with a third of a wave's lanes at a leaf
+// the whole wave almost never leaves early, so the returns buy nothing there.  What a rejected lane computes past its rejection
+// (a division by a zero determinant included) is discarded by the predicate.  The binary64 fallback stays a branch: exact zeros of an
+// edge function are rare.  Used by the LDS-form leaf step (ptrs_hip.hip: lf_leaf_step).
+PT_HD bool tri_test_perm_sel(f3 p0t, f3 p1t, f3 p2t, float sx, float sy, float sz, float t_max, TriHit &h) {
+    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) { // binary64 fallback, shape.rs:124-134
+        e0 = (float)((double)p2t.y * (double)p1t.x - (double)p2t.x * (double)p1t.y);
+        e1 = (float)((double)p0t.y * (double)p2t.x - (double)p0t.x * (double)p2t.y);
+        e2 = (float)((double)p1t.y * (double)p0t.x - (double)p1t.x * (double)p0t.y);
+    }
+    const float det = e0 + e1 + e2;
+    const bool rej_sign = (((e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f)) & ((e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f))) | (det == 0.0f);
+    p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+    const float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    const float lim = t_max * det;
+    const bool rej_range = ((det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < lim))) | ((det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > lim)));
+    float inv_det = 1.0f / det;
+    float t = t_scaled * inv_det;
+    float max_z = max_nz(max_nz(fabs_(p0t.z), fabs_(p1t.z)), fabs_(p2t.z));
+    float delta_z = gamma_err(3) * max_z;
+    float max_x = max_nz(max_nz(fabs_(p0t.x), fabs_(p1t.x)), fabs_(p2t.x));
+    float max_y = max_nz(max_nz(fabs_(p0t.y), fabs_(p1t.y)), fabs_(p2t.y));
+    float delta_x = gamma_err(5) * (max_x + max_z);
+    float delta_y = gamma_err(5) * (max_y + max_z);
+    float delta_e = 2.0f * (gamma_err(2) * max_x * max_y + delta_y * max_x + delta_x * max_y);
+    float max_e = max_nz(max_nz(fabs_(e0), fabs_(e1)), fabs_(e2));
+    float delta_t = 3.0f * (gamma_err(3) * max_e * max_z + delta_e * max_z + delta_z * max_e) * fabs_(inv_det);
+    h.t = t; h.b0 = e0 * inv_det; h.b1 = e1 * inv_det; h.b2 = e2 * inv_det;
+    return !(rej_sign | rej_range) & !(t <= delta_t);
+}
 // returns true and fills h when the ray (o, shear of d, t_max) hits triangle (p0,p1,p2) -- shape.rs:85-185
 PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
     f3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
