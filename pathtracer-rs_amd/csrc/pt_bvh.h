@@ -182,6 +182,13 @@ PT_HD bool leaf_step(const Geom &G, const DScene &sc, uint32_t &leaf, f3 o, cons
     const uint32_t prim = f2u(tc.y), flags = f2u(tc.z);
     ++n_tris;
     TriHit h;
+    if (!ALPHA) { // select form (pt_tri.h: tri_test_perm_sel): no divergent region around the test's rejections and the hit record
+        const bool ok = tri_test_s_sel(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE);
+        hit = hit | ok;
+        t_max = ok ? h.t : t_max;
+        out.prim = ok ? (any_rt ? 0 : (int32_t)prim) : out.prim; out.t = ok ? h.t : out.t; out.b0 = ok ? h.b0 : out.b0; out.b1 = ok ? h.b1 : out.b1; out.b2 = ok ? h.b2 : out.b2; out.flags = ok ? flags : out.flags;
+        return ok & any_rt;
+    }
     if (tri_test_s(o, shear, t_max, p0, p1, p2, h) && !(flags & TRI_DEGENERATE)) {
         if (ALPHA && (flags & TRI_HAS_ALPHA) && alpha_rejects(sc, prim, (int32_t)f2u(tc.w), h)) return false;
         if (any_rt) { out.prim = 0; hit = true; return true; }

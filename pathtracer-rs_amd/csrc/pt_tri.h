@@ -116,6 +116,17 @@ PT_HD bool tri_test_s(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2,
     p2t = mk3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
     return tri_test_perm(p0t, p1t, p2t, S.sx, S.sy, S.sz, t_max, h);
 }
+// tri_test_s with the test proper in select form (tri_test_perm_sel)
+PT_HD bool tri_test_s_sel(f3 o, const RayShear &S, float t_max, f3 p0, f3 p1, f3 p2, TriHit &h) {
+    f3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    const int kz = S.kz;
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    p0t = mk3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
+    p1t = mk3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
+    p2t = mk3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
+    return tri_test_perm_sel(p0t, p1t, p2t, S.sx, S.sy, S.sz, t_max, h);
+}
 // The same with 1/d already at hand (traversal computes it for the slab tests): sz = 1/d[kz] is one of its components --
 // the same division, so the same bits -- which saves one of the six IEEE divisions of a ray's set-up.
 PT_HD RayShear ray_shear_inv(f3 d, f3 inv) {
