@@ -207,7 +207,7 @@ int render_impl(BE &be, const DScene &sc, const HostScene &sc_host_feat, uint32_
     // tail of a kernel or waits for its next launch, the other pass's workgroups fill the machine (two concurrent
     // processes on one MI355X measured +18 % over one).  Film kernels are chained in pass order, so the film is formed
     // by exactly the same additions as with a single pipeline.
-    const uint32_t n_lanes = std::max(1u, be.lanes((uint64_t)(srow1 - srow0) * (uint64_t)g.NX * (uint64_t)g.spp, sc_host_feat.kinds_present, single_pixel != nullptr)); // (the back end may choose by the size of the job)
+    const uint32_t n_lanes = std::max(1u, be.lanes((uint64_t)(srow1 - srow0) * (uint64_t)g.NX * (uint64_t)g.spp, sc_host_feat.kinds_present, single_pixel != nullptr, g.spp)); // (the back end may choose by the size of the job)
     // up to 2^27 paths (~35 GB of path state) per lane: HBM (288 GB) is plentiful, launches and tails are not free.  The back
     // end bounds it by its share of the memory that is free right now, so the library stays embeddable beside other users.
     uint64_t capacity = std::min<uint64_t>(1ull << 27, prm.paths_per_pass ? prm.paths_per_pass : be.auto_capacity(n_lanes, sc_host_feat.kinds_present)); // (2^27: a path slot is 27 bits of a NEE-queue entry, pt_scene.h)

@@ -37,7 +37,7 @@ thread_local std::string g_err;
 // Process-wide tuning knobs (ptrs_set_option).  The library reads no environment variables: an embedding host sets what
 // it needs once; the defaults are the measured best on MI355X.
 struct Options {
-    int lanes = 0;            // concurrent pipeline lanes (own path state, queues and stream each), 1..MAX_LANES; 0 = by the size of the job (HipBackend::lanes)
+    int lanes = 0;            // concurrent pipeline lanes (own path state, queues and stream each), 1..MAX_LANES; 0 = by the size of the job (HipBackend::lanes: 4, 2 under 4 M paths, 1 for one pixel)
     int refill = -1;          // idle-lane threshold of the lane-refill extension kernel; 0 = the fused k_extend; -1 = by scene (32 with phase voting and no alpha masks, else 16)
     int refill_connect = -1;  // the same for the connection kernel (it resolves shadow-only NEE records itself; Cornell: fused k_connect 68 ms, refill 48 ms per frame)
     int stack_lds = 8;        // LDS traversal-stack entries per lane for quad-form scenes: 8 (+ tree top cached in LDS) or 16
@@ -1401,9 +1401,10 @@ struct HipBackend {
     // one lane: 192), colonnade 114.9 (one lane with 16 384 segments: 116.9), classroom 847-852 (852); five and more lanes are
     // slower (182 / 174 / 167 ms for 5 / 6 / 8 on Cornell: the runtime maps streams onto four hardware queues).  A job too small to
     // give four lanes a pass each runs on one lane with 16 384 segments, and so does every single-lane render (the profiled frames).
-    uint32_t lanes(uint64_t job_paths = 0, const bool * = nullptr, bool single_pixel = false) {
+    uint32_t lanes(uint64_t job_paths = 0, const bool * = nullptr, bool single_pixel = false, uint32_t spp = 0xffffffffu) {
         int want = opt.lanes;
-        if (want == 0) want = (job_paths >= (4ull << 20) && !single_pixel) ? 4 : 1; // (render_single_pixel traces spp paths: one lane, the whole workspace)
+        if (want == 0) want = (single_pixel || spp < 2u) ? 1 : (job_paths >= (4ull << 20) ? 4 : 2); // (a small job of ONE sample per pixel is one pass: one lane with its 16 384 segments, where the fused tail takes the whole pass -- the band planner's probe)
+        // (render_single_pixel traces spp paths: one lane, the whole workspace; a job under 4 M paths: two lanes -- with the fused tail a small pass is a handful of launches, and two of them side by side beat one: 1 / 4 rows of the Cornell frame 3.5 / 4.3 -> 2.8 / 3.4 ms)
         if (share > 1 && opt.lanes == 0) want = std::max(1, want / share);        // renders that share a device (ptrs_render_multi replicas) share its hardware queues too
         n_lanes = (uint32_t)(want < 1 ? 1 : (want > MAX_LANES ? MAX_LANES : want));
         return n_lanes;

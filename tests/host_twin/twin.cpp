@@ -81,7 +81,7 @@ struct HostBackend {
         Q.counts = alloc<uint32_t>((size_t)rows * Q_STRIDE); Q.stats = alloc<unsigned long long>(CNT_NUM);
         return PTRS_OK;
     }
-    uint32_t lanes(uint64_t = 0, const bool * = nullptr, bool = false) const { return 1; }
+    uint32_t lanes(uint64_t = 0, const bool * = nullptr, bool = false, uint32_t = 0) const { return 1; }
     uint64_t auto_capacity(uint32_t, const bool *) const { return 1ull << 27; }
     void select(uint32_t) {}
     void pass_begin(const DParams &R_) { R = R_; std::memset(Q.counts, 0, (size_t)rows * Q_STRIDE * 4); }

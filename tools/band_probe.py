@@ -19,7 +19,11 @@ film = torch.zeros((1024, 1024, 4), dtype=torch.float32, device="cuda")
 for _ in range(2):  # warm-up (workspace allocation, clocks)
     integ.render_device(cam, scene, film.data_ptr(), stream=0, row_begin=0, row_end=1024 // N)
 torch.cuda.synchronize()
-t0 = time.perf_counter(); st = integ.render_device(cam, scene, film.data_ptr(), stream=0); torch.cuda.synchronize(); full = time.perf_counter() - t0
+integ.render_device(cam, scene, film.data_ptr(), stream=0); torch.cuda.synchronize()  # (the first full frame grows the workspace from the warm-up band's: not timed -- round 3's and this round's first figures were, which overstated the ratio below)
+fulls = []
+for _ in range(3):
+    t0 = time.perf_counter(); st = integ.render_device(cam, scene, film.data_ptr(), stream=0); torch.cuda.synchronize(); fulls.append(time.perf_counter() - t0)
+full = min(fulls)
 ts = []
 for r in range(N):
     b, e = par.band_for_rank(1024, r, N)
