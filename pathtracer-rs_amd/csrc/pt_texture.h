@@ -34,6 +34,10 @@ PT_HD f3 tex_triangle(const DScene &sc, const DTexture &T, uint32_t level, f2 st
 }
 
 PT_HD f3 tex_lookup_width(const DScene &sc, const DTexture &T, f2 st, float width) {
+    // Footprint zero -- every lookup of a secondary ray (only the camera ray carries differentials, Q9) and every lookup of the environment map:
+    // max(width, 1e-8) is 1e-8, log2 of it -26.58, and level = n_levels - 1 - 26.58 is negative for every pyramid of at most 27 levels (any image
+    // below 2^27 texels a side): the reference's first branch, without the binary64 logarithm that leads there.
+    if (width <= 1e-8f && T.n_levels <= 27) return tex_triangle(sc, T, 0, st);
     float nl = (float)T.n_levels;
     float level = nl - 1.0f + pt_log2f(max_nz(width, 1e-8f));
     if (level < 0.0f) return tex_triangle(sc, T, 0, st);

@@ -193,7 +193,13 @@ PT_HD bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float
     x0 = r0; x1 = r1;
     return true;
 }
-PT_HD int32_t abs_mod(int32_t a, int32_t b) { int32_t r = a - (a / b) * b; return r < 0 ? r + b : r; }
+// a mod b into [0, b) (texture.rs:246-249: `a - (a / b) * b`, plus b when negative).  For a power of two -- every level of a MIP pyramid of
+// a power-of-two image -- that is `a & (b - 1)` for negative a as well (two's complement), the same integer without the ~25-instruction
+// integer division; four of them per bilinear lookup.
+PT_HD int32_t abs_mod(int32_t a, int32_t b) {
+    if ((b & (b - 1)) == 0) return a & (b - 1);
+    int32_t r = a - (a / b) * b; return r < 0 ? r + b : r;
+}
 // math.rs:186-202 on a cdf array: pred(i) = cdf[i] <= u
 PT_HD uint32_t find_interval_cdf(const float *cdf, uint32_t size, float u) {
     uint32_t first = 0, n = size;
