@@ -318,9 +318,18 @@ def test_full_size_properties(ptrs):
     assert np.allclose(w, np.median(w), rtol=0.35) and w.min() > 0
     img = cam.film.to_rgb()
     assert 0.05 < img.mean() < 1.0
+    assert st.tail_launches == 0  # the scene's first render: no survival profile yet, every round is its three launches
     cam.film.clear()
     integ.render(cam, scene)
+    st2 = integ.last_stats
+    assert st2.tail_launches == st2.passes and 1 <= st2.tail_round < 16 and st2.kernel_launches < st.kernel_launches  # ... the second hands its thin rounds to the fused tail
     assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), a["rgb"].view(np.uint32))
+    assert (st2.rays_extension, st2.rays_shadow, st2.rays_mis) == (st.rays_extension, st.rays_shadow, st.rays_mis)
+    cam.film.clear()
+    with ptrs.options(lanes=1, deal=1, tail_at=3):  # one lane of 16 384 segments dealt by image region, the tail from round 3: the same film at full size
+        integ.render(cam, scene)
+    assert np.array_equal(cam.film.pixels["rgb"].view(np.uint32), a["rgb"].view(np.uint32))
+    assert np.array_equal(cam.film.pixels["weight"].view(np.uint32), a["weight"].view(np.uint32))
 
 
 def test_textured_env_matches_oracle(ptrs, orc, scenes):
