@@ -445,6 +445,7 @@ def main():
     ap.add_argument("--rehearse", action="store_true", help="the multi-rank plumbing only (launch, process group, band plan, film gather), no render: runs without a GPU over gloo")
     ap.add_argument("--profile", action="store_true", help="for rocprofv3 runs: render exactly --steps frames on ONE pipeline lane (no counter / warm-up frames, no JSON)")
     ap.add_argument("--tail-at", type=int, default=-2, help="--profile: the round at which the profiled single-lane frames hand over to the fused tail (-1: no tail); tools/prof.sh passes what --print-tail-at printed, so that the profiled frame is launched like the bench's own single-lane frame")
+    ap.add_argument("--profile-lanes", type=int, default=1, help="--profile: pipeline lanes of the profiled frames (1: a kernel has the GPU to itself; 0: the library's default)")
     ap.add_argument("--print-tail-at", action="store_true", help="prints the hand-over round of this workload's single-lane frame (after the frame that teaches the library the scene's survival profile) and exits")
     ap.add_argument("--rays", default="", help="trace workloads: an .npz of ray sets; written (and nothing else done) when it does not exist, read instead of rendering when it does")
     ap.add_argument("--node-order", type=int, default=-1, help="trace workloads: quad-node order behind the LDS-cached top (0 depth-first, 1 treelets)")
@@ -556,7 +557,7 @@ def main():
         return
     if args.profile:
         pin = {} if args.tail_at == -2 else ({"tail": 0} if args.tail_at < 0 else {"tail_at": args.tail_at})
-        with pkg.options(lanes=1, **pin):
+        with pkg.options(lanes=args.profile_lanes, **pin):
             for _ in range(args.steps):
                 st = step(0)
             sync()
