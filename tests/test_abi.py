@@ -72,3 +72,18 @@ def test_options_api():
         assert L.ptrs_last_error()
     import ctypes as C
     assert L.ptrs_get_option(b"no_such_option", C.byref(C.c_int64())) != 0
+
+
+def test_new_entry_points_check_their_arguments(ptrs):
+    """ABI 4's additions refuse bad arguments before they touch a device (no GPU needed): the band planner's probe, the division
+    self-test, and the build id is the hash of this tree's kernel sources and flags."""
+    import importlib
+    L = ptrs.load_library()
+    assert L.ptrs_render_row_cost(None, None, None, None, None) != 0 and b"null" in L.ptrs_last_error()
+    bad = C.c_uint64(0)
+    L.ptrs_selftest_div3.argtypes = [C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
+    assert L.ptrs_selftest_div3(0, 9, 1, 1, C.byref(bad), None, None) != 0   # no such mode
+    assert L.ptrs_selftest_div3(0, 0, 0, 1, C.byref(bad), None, None) != 0   # nothing to test
+    assert L.ptrs_selftest_div3(0, 0, 1, 1, None, None, None) != 0           # nowhere to put the answer
+    assert ptrs.build_id() == importlib.import_module("pathtracer-rs_amd.build").source_hash()
+    assert len(ptrs.build_id()) == 16
