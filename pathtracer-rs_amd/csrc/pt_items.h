@@ -287,7 +287,11 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     const SpawnPair sp = spawn_pair(s.p, s.p_error, s.n); // every ray and pdf query of this vertex leaves from one of two offset points
     // ---- direct lighting: uniform_sample_one_light + estimate_direct up to the scene queries ----
     const uint32_t NS = BSDF_ALL & ~BSDF_SPECULAR;
+#if defined(PTRS_ABL_SHADE_HALF) && PTRS_ABL_SHADE_HALF == 2
+    const bool do_nee = false; // diagnostic build (tools/ablate.sh; timing only, wrong radiance): the vertex WITHOUT its next-event estimation
+#else
     const bool do_nee = bsdf_num(bsdf, NS) > 0 && sc.n_lights > 0;
+#endif
     if (do_nee != nee_guess) draw_vertex(X, S, stv, false, D); // only a lobeless Substrate gets here (do_nee false, nee_guess true): its draws start at the vertex's first dimension
     if (do_nee) {
         DLight Lt; // a register copy of the light's record (LDS-resident for scenes with few lights): the fields its kind reads are fetched together
@@ -360,7 +364,11 @@ PT_HD ShadeResult shade_item(const DParams &R, const DSampler &S, const DCamera 
     uint32_t dim = D.after_cont;
     f3 wi = splat3(0.0f);
     float pdf = 0.0f; uint32_t flags = 0;
+#if defined(PTRS_ABL_SHADE_HALF) && PTRS_ABL_SHADE_HALF == 1
+    f3 f = splat3(0.0f); // diagnostic build: the vertex WITHOUT its continuation (every path ends here)
+#else
     f3 f = bsdf_sample_f(bsdf, wo, wi, mk2(u_tail[0], u_tail[1]), pdf, BSDF_ALL, flags);
+#endif
     bool alive = true;
     if (D.err_cont) { out.err_dim = true; alive = false; } // a draw outside the sampler's dimensions: the reference panics (Sobol') / leaves the tables (stratified)
     if (is_black(f) || pdf == 0.0f) alive = false;
