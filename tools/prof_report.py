@@ -124,12 +124,14 @@ def main():
         json.dump(dg, open(arg("--json", "pmc.json"), "w"), indent=1, sort_keys=True)
         dg.pop("_meta")
     f = lambda x: "  -  " if x is None else "%5.2f" % x
-    print("%-34s %5s %8s %7s %6s %8s %6s %11s %5s %5s %5s %6s %6s %6s %6s %5s  %s" % ("kernel", "calls", "total_ms", "avg_ms", "pct", "HBM GB/s", "lanes", "VALU lo..hi", "issue", "wait", "stall", "w/SIMD", "S/V", "LDSbz", "LDScf", "L2hit", "bound"))
+    print("%-34s %5s %8s %7s %6s %8s %6s %11s %5s %5s %5s %6s %6s %6s %6s %6s %6s %5s  %s" % ("kernel", "calls", "total_ms", "avg_ms", "pct", "belowL2", "lanes", "VALU lo..hi", "issue", "wait", "stall", "LDSstl", "w/SIMD", "S/V", "VM/V", "LDSbz", "LDScf", "L2hit", "bound"))
     for n, o in sorted(dg.items(), key=lambda kv: -kv[1]["total_ms"]):
-        print("%-34s %5d %8.2f %7.3f %6.2f %8.0f %6.1f %5.2f..%4.2f %5.2f %5.2f %5.2f %6.2f %6.2f %s %6.2f %5.2f  %s" % (
+        print("%-34s %5d %8.2f %7.3f %6.2f %8.0f %6.1f %5.2f..%4.2f %5.2f %5.2f %5.2f %6.3f %6.2f %6.2f %6.3f %s %6.2f %5.2f  %s" % (
             n, o["calls"], o["total_ms"], o["avg_ms"], o["pct_of_gpu_time"], o["hbm_gbs"], o["lanes_per_valu_inst"], o["valu_pipe_frac_lo"], o["valu_pipe_frac_hi"],
-            o["wave_issue_frac"], o["wave_wait_frac"], o["wave_stall_frac"], o["waves_resident_per_simd"], o["salu_per_valu"], f(o["lds_busy_frac"]),
+            o["wave_issue_frac"], o["wave_wait_frac"], o["wave_stall_frac"], o["wave_wait_lds_frac"], o["waves_resident_per_simd"], o["salu_per_valu"],
+            (o["vmem_rd_insts"] + o["vmem_wr_insts"]) / max(o["valu_insts"], 1.0), f(o["lds_busy_frac"]),
             o["lds_conflict_cycles_per_lds_inst"], o["l2_hit_rate"], o["bound"]))
+    print("(belowL2: GB/s of 2 x FETCH_SIZE + WRITE_SIZE, bytes below L2 = HBM + Infinity Cache; LDSstl: SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES, the LDS share of `stall`; VM/V: vector-memory per vector-ALU instruction)")
 
 
 if __name__ == "__main__":
