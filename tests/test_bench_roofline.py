@@ -71,3 +71,23 @@ def test_valu_ceiling_table_is_the_measured_one():
     at4 = lambda inst: next(r["per_cycle_per_simd"] for r in j["rows"] if r["inst"] == inst and r["chains"].startswith("8") and r["waves_per_simd"] == 4)
     assert abs(1.0 / at4("v_max_f32") - bench.CLASS_B_CYCLES) < 0.5 and abs(1.0 / at4("v_cmp_lt_f32_e64 -> SGPR pair") - bench.CLASS_B_CYCLES) < 0.5  # the model's 4.2 cycles: the rate at 2-6 waves per SIMD
     assert at4("mix v_max_f32 : v_fma_f32 = 1 : 1") > 0.38  # the two classes issue side by side
+
+
+def test_fetch_size_calibration_is_what_the_reports_apply():
+    """profiles/r04_fetch_calib.json (tools/fetch_calib.hip under rocprofv3 on MI355X): FETCH_SIZE is half of TCC_MISS x 128 B for this
+    library's two access shapes, Infinity-Cache-resident tables included -- and every r04 counter summary doubles it accordingly."""
+    j = json.load(open(os.path.join(ROOT, "profiles", "r04_fetch_calib.json")))
+    c = j["_conclusions"]
+    assert abs(c["factor_stream_16B_per_lane"] - 2.0) < 0.01
+    assert all(abs(v - 2.0) < 0.01 for v in c["factor_gather_128B_records_vs_l2_misses"].values()) and c["infinity_cache_hits_counted"] is True
+    for case in ("stream_2GB", "gather_64MB_dependent", "gather_2GB_dependent"):
+        k = j[case]["counters"]
+        assert abs(k["FETCH_SIZE"] * 1024.0 / (k["TCC_MISS_sum"] * 64.0) - 1.0) < 0.01            # = TCC_MISS x 64 B
+        assert abs(k["TCC_EA0_RDREQ_128B_sum"] / k["TCC_EA0_RDREQ_sum"] - 1.0) < 0.01                # every memory-side read is a 128-byte request
+        assert abs(k["TCC_EA0_RDREQ_DRAM_sum"] / k["TCC_EA0_RDREQ_sum"] - 1.0) < 0.01                # "DRAM" names the address space: no counter separates the Infinity Cache
+    assert j["gather_64MB_dependent"]["record_visits_per_s"] > j["gather_2GB_dependent"]["record_visits_per_s"] > 3e10
+    for w in ("cornell", "colonnade", "classroom", "trace-colonnade", "trace-classroom"):
+        raw = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % w)))
+        for name, k in raw.items():
+            if not name.startswith("_"):
+                assert k["fetch_size_factor"] == 2.0 and abs(k["hbm_bytes"] - (k["fetch_bytes_calibrated"] + k["write_bytes"])) <= 1e-6 * max(k["hbm_bytes"], 1.0)
