@@ -686,3 +686,21 @@ def test_row_cost_probe_counts_every_ray_once(ptrs):
         assert np.array_equal(cost, cost3)
         b8 = par.plan_bands(h, 4, cost)
         assert b8[0] == 0 and b8[-1] == h and par.plan_gain(h, 4, cost) >= 1.0 - 1e-9
+
+
+def test_default_schedule_with_tail_matches_oracle_per_sample(ptrs, orc):
+    """The library's DEFAULT policy on a job big enough for it (4.9 M paths: four pipeline lanes of 2 048 segments), first without a
+    survival profile (every round its three launches), then with (thin rounds in the fused tail): every sample's radiance equal to
+    the oracle's, bit for bit, both times -- the shipped schedule held against the oracle directly, no option set."""
+    cam, scene = ptrs.import_scene(CORNELL, (192, 192))
+    integ = ptrs.PathIntegrator(ptrs.SamplerBuilder(128, cam.film.get_sample_bounds()), 15)
+    _, ref, ost = orc.OracleScene(scene).render(cam, orc.make_params(192, 192, 128, 15), n_threads=16, want_samples=True)
+    for k in range(2):
+        cam.film.clear()
+        got = integ.render(cam, scene, want_samples=True)
+        st = integ.last_stats
+        assert st.lanes == 4 and st.queue_segments == 2048 and st.passes == 4
+        assert (st.tail_launches == 0) if k == 0 else (st.tail_launches == 4 and 1 <= st.tail_round < 16)
+        assert (st.rays_extension, st.rays_shadow, st.rays_mis) == (ost.rays_extension, ost.rays_shadow, ost.rays_mis)
+        bad = (got.view(np.uint32) != ref.view(np.uint32)).any(axis=-1)
+        assert bad.sum() == 0, "%d of %d samples differ (render %d)" % (bad.sum(), bad.size, k)
